@@ -1,0 +1,115 @@
+"""Portable, seeded state_dict generator (test infrastructure).
+
+The reference ships no trained checkpoint and a full state_dict is 44.7 MB, so
+the goldens are pinned to weights that both boxes can regenerate bit-for-bit:
+``numpy.random.RandomState(seed)`` (the legacy MT19937 stream numpy freezes
+across versions) walks the reference's ``state_dict`` key list in registration
+order (diffusion.py:16-107 / conditional_diffusion.py:19-113) and fills every
+tensor.  BatchNorm statistics are deliberately non-trivial (at default init an
+eval-mode BN is ~identity and would hide bugs).
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+TIME_DIM = 256
+
+# (name, cin, cout) of the six two-conv stages, diffusion.py:32-95
+_STAGES = [
+    ("enc1", 64, 128),
+    ("enc2", 128, 256),
+    ("enc3", 256, 512),
+    ("dec3", 1024, 256),
+    ("dec2", 512, 128),
+    ("dec1", 256, 64),
+]
+
+
+def key_shapes(cond: bool, num_classes: int = 10, time_dim: int = TIME_DIM):
+    """Ordered (key, shape, kind) list == reference ``state_dict()`` order."""
+    out = []
+
+    def conv(name, cin, cout, k):
+        out.append((f"{name}.weight", (cout, cin, k, k), "conv_w"))
+        out.append((f"{name}.bias", (cout,), "bias"))
+
+    def bn(name, c):
+        out.append((f"{name}.weight", (c,), "bn_w"))
+        out.append((f"{name}.bias", (c,), "bn_b"))
+        out.append((f"{name}.running_mean", (c,), "bn_rm"))
+        out.append((f"{name}.running_var", (c,), "bn_rv"))
+        out.append((f"{name}.num_batches_tracked", (), "bn_nbt"))
+
+    out.append(("time_embedding.0.weight", (time_dim, 1), "lin_w"))
+    out.append(("time_embedding.0.bias", (time_dim,), "bias"))
+    out.append(("time_embedding.2.weight", (time_dim, time_dim), "lin_w"))
+    out.append(("time_embedding.2.bias", (time_dim,), "bias"))
+    if cond:
+        out.append(("class_embedding.weight", (num_classes, time_dim), "emb"))
+    conv("initial_conv", 1, 64, 3)
+    for name, cin, cout in _STAGES[:3]:
+        conv(f"{name}.0", cin, cout, 3)
+        bn(f"{name}.1", cout)
+        conv(f"{name}.3", cout, cout, 3)
+        bn(f"{name}.4", cout)
+    conv("bottleneck.0", 512, 512, 3)
+    bn("bottleneck.1", 512)
+    for name, cin, cout in _STAGES[3:]:
+        conv(f"{name}.0", cin, cout, 3)
+        bn(f"{name}.1", cout)
+        conv(f"{name}.3", cout, cout, 3)
+        bn(f"{name}.4", cout)
+    conv("final_conv", 64, 1, 3)
+    conv("time_proj1", time_dim, 128, 1)
+    conv("time_proj2", time_dim, 256, 1)
+    conv("time_proj3", time_dim, 512, 1)
+    return out
+
+
+def make_state_dict(seed: int = 0, cond: bool = False, time_scale: float = 1.0):
+    """Reference-format state_dict (OIHW conv weights, fp32, int64 counters).
+
+    ``time_scale`` multiplies ``time_embedding.0.weight`` only; 1.0 reproduces
+    the reference's un-normalised-t regime (pre-activations ~ t * N(0,2)).
+    """
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape, kind in key_shapes(cond):
+        if kind in ("conv_w", "lin_w"):
+            fan_in = int(np.prod(shape[1:]))
+            a = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+            if key == "time_embedding.0.weight":
+                # raw t in [0, 1000) feeds this layer (diffusion.py:111); keep the
+                # pre-activation O(1)..O(10) so SiLU is exercised in its curved part
+                a = a * (time_scale / 100.0)
+        elif kind == "bias":
+            a = rs.standard_normal(shape) * 0.01
+        elif kind == "bn_w":
+            a = 1.0 + rs.standard_normal(shape) * 0.1
+        elif kind == "bn_b":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rm":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rv":
+            a = 1.0 + np.abs(rs.standard_normal(shape) * 0.1)
+        elif kind == "bn_nbt":
+            sd[key] = torch.tensor(1, dtype=torch.int64)
+            continue
+        elif kind == "emb":
+            a = rs.standard_normal(shape)
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return sd
+
+
+def state_dict_sha256(sd) -> str:
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        if v.dtype == torch.float32:
+            h.update(v.contiguous().numpy().tobytes())
+    return h.hexdigest()

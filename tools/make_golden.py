@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference
+scripts import torchvision / wandb at module scope for their data and logging
+code; those packages are not installed here and are never reached by the hot
+path, so inert stub modules are registered before loading each script by path
+(SURVEY.md section 8(c)).  Nothing is written under /root/reference
+(``sys.dont_write_bytecode``).  Output: small .npz vectors only - the weights
+are regenerated on both sides by oracle/weights.py::make_state_dict.
+
+    python tools/make_golden.py            # writes tests/golden/
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.weights import make_state_dict, state_dict_sha256  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load_reference(script):
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms")
+    tv.datasets = _stub("torchvision.datasets")
+    tv.utils = _stub("torchvision.utils")
+    _stub("wandb")
+    spec = importlib.util.spec_from_file_location(
+        "ref_" + script.replace(".py", ""), os.path.join(REF, script)
+    )
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def inputs(seed, B, cond):
+    """Portable synthetic MNIST-shaped inputs (numpy legacy RNG)."""
+    rs = np.random.RandomState(1000 + seed)
+    x0 = (rs.rand(B, 1, 28, 28) * 2 - 1).astype(np.float32)
+    noise = rs.standard_normal((B, 1, 28, 28)).astype(np.float32)
+    t = rs.randint(0, 1000, size=(B,)).astype(np.int64)
+    # make sure the extremes are present
+    t[0], t[1] = 0, 999
+    y = rs.randint(0, 10, size=(B,)).astype(np.int64) if cond else None
+    return x0, noise, t, y
+
+
+def build(mod, cond, sd):
+    model = mod.NoiseModel()
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def bn_buffers(model):
+    return {
+        k.replace(".", "__"): v.detach().numpy().copy()
+        for k, v in model.state_dict().items()
+        if "running_" in k or "num_batches" in k
+    }
+
+
+def fwd_fixture(mod, cond, mode, B, seed=0, time_scale=1.0, tag=None):
+    sd = make_state_dict(seed, cond, time_scale=time_scale)
+    model = build(mod, cond, sd)
+    fp = mod.ForwardProcess()
+    x0, noise, t, y = inputs(seed, B, cond)
+    x0t, nt, tt = torch.from_numpy(x0), torch.from_numpy(noise), torch.from_numpy(t)
+    # q_sample with the caller's noise: reference expression diffusion.py:180-190
+    a = torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1, 1, 1)
+    b = torch.sqrt(1.0 - fp.alphas_cumprod[tt]).view(-1, 1, 1, 1)
+    x_t = a * x0t + b * nt
+    model.train(mode == "train")
+    args = (x_t, tt) + ((torch.from_numpy(y),) if cond else ())
+    with torch.no_grad():
+        eps = model(*args)
+        loss = F.mse_loss(eps, nt)
+    d = dict(x0=x0, noise=noise, t=t, x_t=x_t.numpy(), eps_hat=eps.numpy(),
+             loss=np.float64(loss.item()), seed=seed, time_scale=time_scale)
+    if cond:
+        d["y"] = y
+    if mode == "train":
+        d.update(bn_buffers(model))
+    name = tag or f"fwd_B{B}_{mode}_{'cond' if cond else 'uncond'}"
+    np.savez(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", loss.item())
+
+
+def summarize(v, nsamp=512):
+    v = v.detach().contiguous().view(-1)
+    idx = torch.linspace(0, v.numel() - 1, min(nsamp, v.numel())).long()
+    return dict(sum=v.double().sum().item(), asum=v.double().abs().sum().item(),
+                idx=idx.numpy(), val=v[idx].numpy())
+
+
+def taps_fixture(mod, B=2, seed=0):
+    """Every intermediate of NoiseModel.forward, recomputed with the reference's
+    own sub-modules; the final tensor is asserted bit-identical to model(x, t)."""
+    cond = False
+    sd = make_state_dict(seed, cond)
+    m = build(mod, cond, sd).eval()
+    x0, noise, t, _ = inputs(seed, B, cond)
+    fp = mod.ForwardProcess()
+    tt = torch.from_numpy(t)
+    x = (torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * torch.from_numpy(x0)
+         + torch.sqrt(1 - fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * torch.from_numpy(noise))
+    taps = {}
+    with torch.no_grad():
+        te = m.time_embedding(tt.unsqueeze(-1).float())
+        taps["emb"] = te
+        te4 = te.view(-1, m.time_dim, 1, 1)
+        taps["x0"] = m.initial_conv(x)
+        taps["e1"] = m.enc1(taps["x0"]); taps["e1p"] = m.pool(taps["e1"])
+        taps["e2"] = m.enc2(taps["e1p"]); taps["e2p"] = m.pool(taps["e2"])
+        taps["e3"] = m.enc3(taps["e2p"]); taps["e3p"] = m.pool(taps["e3"])
+        taps["b"] = m.bottleneck(taps["e3p"])
+        taps["t1"], taps["t2"], taps["t3"] = m.time_proj1(te4), m.time_proj2(te4), m.time_proj3(te4)
+        taps["up_b"] = m.up(taps["b"])
+        taps["e3a"] = F.interpolate(taps["e3"] + taps["t3"], size=(8, 8), mode="bilinear", align_corners=True)
+        taps["d3"] = m.dec3(torch.cat([taps["up_b"], taps["e3a"]], dim=1))
+        taps["up_d3"] = m.up(taps["d3"])
+        taps["e2a"] = F.interpolate(taps["e2"] + taps["t2"], size=(16, 16), mode="bilinear", align_corners=True)
+        taps["d2"] = m.dec2(torch.cat([taps["up_d3"], taps["e2a"]], dim=1))
+        taps["up_d2"] = m.up(taps["d2"])
+        taps["e1a"] = F.interpolate(taps["e1"] + taps["t1"], size=(32, 32), mode="bilinear", align_corners=True)
+        taps["d1"] = m.dec1(torch.cat([taps["up_d2"], taps["e1a"]], dim=1))
+        taps["d1a"] = F.interpolate(taps["d1"], size=(28, 28), mode="bilinear", align_corners=True)
+        taps["out"] = m.final_conv(taps["d1a"])
+        ref_out = m(x, tt)
+    assert torch.equal(ref_out, taps["out"]), "tap replay diverged from NoiseModel.forward"
+    d = dict(x=x.numpy(), t=t, seed=seed)
+    for k, v in taps.items():
+        s = summarize(v)
+        d[f"{k}__shape"] = np.array(v.shape)
+        for kk, vv in s.items():
+            d[f"{k}__{kk}"] = vv
+    np.savez(os.path.join(OUT, f"taps_B{B}.npz"), **d)
+    print("taps ok", len(taps))
+
+
+def grad_fixture(mod, cond, B, seed=0):
+    sd = make_state_dict(seed, cond)
+    model = build(mod, cond, sd).train()
+    fp = mod.ForwardProcess()
+    x0, noise, t, y = inputs(seed, B, cond)
+    tt, nt = torch.from_numpy(t), torch.from_numpy(noise)
+    x_t = (torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * torch.from_numpy(x0)
+           + torch.sqrt(1 - fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * nt)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)   # diffusion.py:211
+    args = (x_t, tt) + ((torch.from_numpy(y),) if cond else ())
+    eps = model(*args)
+    loss = F.mse_loss(eps, nt)                            # diffusion.py:231
+    opt.zero_grad(); loss.backward()
+    d = dict(x_t=x_t.numpy(), noise=noise, t=t, loss=np.float64(loss.item()), seed=seed,
+             eps_hat=eps.detach().numpy())
+    if cond:
+        d["y"] = y
+    for k, p in model.named_parameters():
+        g = p.grad.detach().contiguous().view(-1)
+        kk = k.replace(".", "__")
+        d[f"gnorm__{kk}"] = np.float64(g.double().norm().item())
+        d[f"ghead__{kk}"] = g[:64].numpy().copy()
+        d[f"gsum__{kk}"] = np.float64(g.double().sum().item())
+    d.update({"buf__" + k: v for k, v in bn_buffers(model).items()})
+    opt.step()                                            # diffusion.py:236
+    for k, p in model.named_parameters():
+        kk = k.replace(".", "__")
+        pv = p.detach().contiguous().view(-1)
+        d[f"adam_head__{kk}"] = pv[:64].numpy().copy()
+        d[f"adam_sum__{kk}"] = np.float64(pv.double().sum().item())
+    name = f"grad_B{B}_{'cond' if cond else 'uncond'}"
+    np.savez(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "loss", loss.item())
+
+
+def sample_fixture(mod, cond, T, n, seed=0, rng_seed=1234, keep=None):
+    sd = make_state_dict(seed, cond)
+    model = build(mod, cond, sd)
+    fp = mod.ForwardProcess(num_timesteps=T)
+    y = torch.arange(n) % 10 if cond else None
+    torch.manual_seed(rng_seed)
+    if cond:
+        final = mod.sample(model, fp, torch.device("cpu"), n_samples=n, y=y)
+    else:
+        final = mod.sample(model, fp, torch.device("cpu"), n_samples=n)
+    assert model.training is False     # sample() leaves the model in eval mode
+    # replay the RNG consumption order of sample(): x_T, then z for t=T-1..1
+    torch.manual_seed(rng_seed)
+    x_T = torch.randn(n, 1, 28, 28)
+    zs = np.zeros((T, n, 1, 28, 28), np.float32)
+    for t in reversed(range(T)):
+        if t > 0:
+            zs[t] = torch.randn_like(x_T).numpy()
+    # re-run with the recorded noise to capture intermediates and prove the replay
+    x = x_T.clone()
+    snaps = {}
+    keep = set(keep or [])
+    with torch.no_grad():
+        for t in reversed(range(T)):
+            tt = torch.full((n,), t, dtype=torch.long)
+            eps = model(x, tt, y) if cond else model(x, tt)
+            alpha, ac, beta = fp.alphas[t], fp.alphas_cumprod[t], fp.betas[t]
+            z = torch.from_numpy(zs[t])
+            x = (1 / torch.sqrt(alpha)) * (x - ((1 - alpha) / torch.sqrt(1 - ac)) * eps) + torch.sqrt(beta) * z
+            if t in keep:
+                snaps[t] = x.numpy().copy()
+    assert torch.equal(x, final), "RNG replay of sample() is not bit-exact"
+    d = dict(x_T=x_T.numpy(), final=final.numpy(), T=T, n=n, seed=seed, rng_seed=rng_seed)
+    if cond:
+        d["y"] = y.numpy()
+    if T <= 50:
+        d["zs"] = zs
+    else:
+        # full noise would be 12.5 MB: keep it regenerable instead (torch CPU
+        # generator stream) and pin a few slices of it
+        d["zs_head"] = zs[T - 3:]
+        d["zs_tail"] = zs[1:4]
+    for t, v in snaps.items():
+        d[f"x_after_t{t}"] = v
+    name = f"sample_T{T}_n{n}_{'cond' if cond else 'uncond'}"
+    np.savez(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "final mean/std", final.mean().item(), final.std().item())
+
+
+def schedule_fixture(mod):
+    fp = mod.ForwardProcess()
+    c1 = 1 / torch.sqrt(fp.alphas)
+    c2 = (1 - fp.alphas) / torch.sqrt(1 - fp.alphas_cumprod)
+    sig = torch.sqrt(fp.betas)
+    np.savez(os.path.join(OUT, "schedule.npz"), betas=fp.betas.numpy(), alphas=fp.alphas.numpy(),
+             alphas_cumprod=fp.alphas_cumprod.numpy(), c1=c1.numpy(), c2=c2.numpy(), sigma=sig.numpy(),
+             sqrt_ac=torch.sqrt(fp.alphas_cumprod).numpy(),
+             sqrt_1mac=torch.sqrt(1.0 - fp.alphas_cumprod).numpy())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    unc = load_reference("diffusion.py")
+    con = load_reference("conditional_diffusion.py")
+    with open(os.path.join(OUT, "weights.sha256"), "w") as f:
+        f.write(f"uncond seed0 {state_dict_sha256(make_state_dict(0, False))}\n")
+        f.write(f"cond seed0 {state_dict_sha256(make_state_dict(0, True))}\n")
+    schedule_fixture(unc)
+    fwd_fixture(unc, False, "train", 64)
+    fwd_fixture(unc, False, "eval", 64)
+    fwd_fixture(con, True, "train", 16)
+    fwd_fixture(con, True, "eval", 16)
+    fwd_fixture(unc, False, "eval", 8, time_scale=100.0, tag="fwd_B8_eval_rawt")
+    taps_fixture(unc, B=2)
+    grad_fixture(unc, False, 64)
+    grad_fixture(con, True, 16)
+    sample_fixture(unc, False, 20, 4, keep=[19, 10, 1, 0])
+    sample_fixture(con, True, 20, 4, keep=[19, 10, 1, 0])
+    sample_fixture(unc, False, 1000, 4, keep=[999, 750, 500, 250, 1, 0])
+
+
+if __name__ == "__main__":
+    main()
