@@ -1,0 +1,233 @@
+/*
+ * tdx.h - C ABI of libtdx.so: the MI355X (gfx950) implementation of the
+ * tiny-diffusion DDPM hot path.
+ *
+ * The reference (david-wb/tiny-diffusion) is pure Python and defines no FFI;
+ * its boundary for this path is the Python call surface
+ *     NoiseModel.forward(x, t[, y])      diffusion.py:109 / conditional_diffusion.py:115
+ *     ForwardProcess.q_sample(...)       diffusion.py:177
+ *     sample(...) reverse loop           diffusion.py:254-276
+ * Each entry point below names the reference lines it replaces.  The host side
+ * (the tiny_diffusion_amd python package) mirrors that Python surface and calls these
+ * through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every function returns int: 0 = ok, >0 = hipError_t, <0 = TDX_E_*.
+ *     Nothing throws.
+ *   - all data pointers are caller-owned DEVICE pointers; the library never
+ *     allocates on the hot path (scratch comes from a caller workspace sized
+ *     by tdx_unet_workspace_bytes).
+ *   - every launch takes an explicit hipStream_t (as void*).
+ *   - activations are fp32, channels-last (N,H,W,C); (N,1,H,W) model inputs
+ *     and outputs are bit-identical in both layouts.
+ *   - parameters are passed in the REFERENCE layout (OIHW conv weights, the
+ *     state_dict order of diffusion.py:16-107); packing is done on device.
+ */
+#ifndef TDX_H
+#define TDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDX_VERSION 100 /* 0.1.0 */
+
+#define TDX_E_BADARG (-1)   /* null pointer, size <= 0, batch > plan capacity ... */
+#define TDX_E_SHAPE (-2)    /* shape the kernel family does not cover */
+#define TDX_E_WORKSPACE (-3) /* workspace too small */
+#define TDX_E_STATE (-4)    /* backward without a saved forward, etc. */
+
+typedef void* tdx_stream_t; /* hipStream_t */
+
+int tdx_version(void);
+const char* tdx_error_string(int code);
+
+/* ---- forward process / reverse step (HBM-bound elementwise) ------------- */
+
+/* q_sample, diffusion.py:177-190: x_t = sqrt_ac[t]*x0 + sqrt_1mac[t]*noise.
+ * sqrt_ac / sqrt_1mac: device tables (T,) = sqrt(alphas_cumprod), sqrt(1-alphas_cumprod)
+ * computed by the host with the reference's fp32 expressions.
+ * 12 B/element algorithmic traffic (read x0, noise; write x_t). */
+int tdx_q_sample(const float* x0, const float* noise, const int64_t* t,
+                 const float* sqrt_ac, const float* sqrt_1mac, float* x_t,
+                 int batch, int per_sample, tdx_stream_t stream);
+
+/* q_sample with in-kernel Philox4x32-10 + Box-Muller noise (throughput mode;
+ * statistically equivalent to, not bit-identical with, torch.randn).
+ * Writes both x_t and the noise (the training target, diffusion.py:225/231). */
+int tdx_q_sample_philox(const float* x0, const int64_t* t, const float* sqrt_ac,
+                        const float* sqrt_1mac, float* x_t, float* noise_out,
+                        int batch, int per_sample, uint64_t seed, uint64_t offset,
+                        tdx_stream_t stream);
+
+/* One reverse step, diffusion.py:272-274:
+ *   x_out = c1*(x - c2*eps) + sigma*z        (z == NULL means z = 0, the t == 0 branch)
+ * coef: device table (T,3) of (c1,c2,sigma) = (1/sqrt(alpha), (1-alpha)/sqrt(1-acp), sqrt(beta));
+ * t_idx: device pointer to the current step index (int32) so that a captured
+ * graph can be replayed for every t.  16 B/element (read x, eps, z; write x). */
+int tdx_p_sample_step(float* x_out, const float* x, const float* eps, const float* z,
+                      const float* coef, const int32_t* t_idx, int64_t n,
+                      tdx_stream_t stream);
+
+/* Same, with in-kernel Philox noise (z generated, never stored): 12 B/element. */
+int tdx_p_sample_step_philox(float* x_out, const float* x, const float* eps,
+                             const float* coef, const int32_t* t_idx, int64_t n,
+                             uint64_t seed, tdx_stream_t stream);
+
+/* mean((a-b)^2) -> out[0] (F.mse_loss, diffusion.py:231) and its gradient
+ * d_a = 2*(a-b)/n * gscale.  Either output may be NULL. */
+int tdx_mse_loss(const float* a, const float* b, float* loss_out, float* d_a,
+                 float gscale, int64_t n, tdx_stream_t stream);
+
+/* Adam, torch defaults (diffusion.py:211/236): one fused pass over a flat
+ * parameter buffer, 28 B/param.  step is the 1-based step count. */
+int tdx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                  float grad_scale, tdx_stream_t stream);
+
+/* ---- building blocks (exported for unit tests and re-use) --------------- */
+
+/* OIHW (Cout,Cin,3,3) -> forward pack [Cout][9][Cin] and dgrad pack
+ * [Cin][9 flipped][Cout].  Either destination may be NULL. */
+int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout, int cin,
+                     tdx_stream_t stream);
+
+/* Flags for tdx_conv3x3_fwd */
+#define TDX_CONV_IN_BNRELU 1   /* input is a pre-BN tensor: apply relu(x*in_scale+in_shift) on load */
+#define TDX_CONV_OUT_BNRELU 2  /* epilogue: out = relu((acc+bias)*out_scale+out_shift)  (inference) */
+#define TDX_CONV_OUT_STATS 4   /* epilogue: also emit per-tile per-channel (sum, sumsq) partials */
+
+/* 3x3, pad 1, stride 1 convolution as an implicit GEMM on fp32 MFMA
+ * (nn.Conv2d(cin,cout,3,padding=1), diffusion.py:28-98), NHWC.
+ *   in  (B,H,W,cin)  wpk [cout][9][cin]  bias (cout) or NULL  out (B,H,W,cout)
+ * With the dgrad pack and the roles of cin/cout swapped the same entry point
+ * computes the input gradient.  cin % 32 == 0, cout % 64 == 0.
+ * stats_partial (when TDX_CONV_OUT_STATS): [tdx_conv3x3_stat_tiles(...)][2][cout]. */
+int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,
+                    int B, int H, int W, int cin, int cout, int flags,
+                    const float* in_scale, const float* in_shift,
+                    const float* out_scale, const float* out_shift,
+                    float* stats_partial, tdx_stream_t stream);
+int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
+
+/* Weight gradient of the same convolution:
+ *   dw_slabs[s][cout][9][cin] partial sums over pixel chunk s (split-K, deterministic)
+ * followed by tdx_conv3x3_wgrad_reduce -> OIHW gradient.  `in` may be a pre-BN
+ * tensor (TDX_CONV_IN_BNRELU with in_scale/in_shift). */
+int tdx_conv3x3_wgrad_splits(int B, int H, int W, int cin, int cout);
+int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_slabs,
+                      int B, int H, int W, int cin, int cout, int flags,
+                      const float* in_scale, const float* in_shift, tdx_stream_t stream);
+int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, int cout, int cin,
+                             tdx_stream_t stream);
+
+/* BatchNorm2d (diffusion.py:34 ...): turn the conv epilogue's partials into
+ * per-channel scale/shift (+ saved mean/rstd) and update the running buffers.
+ *   training != 0: batch statistics (biased var to normalise, unbiased into
+ *                  running_var, momentum 0.1, num_batches_tracked += 1)
+ *   training == 0: scale/shift from the running statistics. */
+int tdx_bn_finalize(const float* stats_partial, int tiles, int64_t count, int C,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale, float* shift, float* save_mean, float* save_rstd,
+                    int training, tdx_stream_t stream);
+
+/* BN+ReLU backward, in place on g (B*H*W, C):
+ *   gz = g * [y*scale+shift > 0];  dgamma = sum gz*xhat;  dbeta = sum gz
+ *   training: g <- gamma*rstd*(gz - dbeta/N - xhat*dgamma/N)   else g <- gz*scale
+ * Also returns dbias = column sums of the result (gradient of the conv bias). */
+int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C,
+                    const float* scale, const float* shift, const float* save_mean,
+                    const float* save_rstd, const float* gamma,
+                    float* dgamma, float* dbeta, float* dbias, float* scratch,
+                    int training, tdx_stream_t stream);
+size_t tdx_bn_relu_bwd_scratch_floats(int64_t rows, int C);
+
+/* MaxPool2d(2, ceil_mode=True) (diffusion.py:101) over relu(y*scale+shift)
+ * (scale == NULL: raw input).  (B,H,W,C) -> (B,ceil(H/2),ceil(W/2),C). */
+int tdx_maxpool2_ceil_fwd(const float* y, const float* scale, const float* shift, float* out,
+                          int B, int H, int W, int C, tdx_stream_t stream);
+/* g_in = (skip_grad or 0) + route(g_out to the first arg-max of each window). */
+int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const float* shift,
+                          const float* g_out, const float* skip_grad, float* g_in,
+                          int B, int H, int W, int C, tdx_stream_t stream);
+
+/* Bilinear resize, align_corners=True (nn.Upsample / F.interpolate,
+ * diffusion.py:102, 135-159) of relu(y*scale+shift) + addend[n][c]
+ * (scale == NULL: raw input; addend == NULL: none).  The destination may be a
+ * channel slice of a wider tensor: out[(pixel)*out_cstride + out_coff + c]. */
+int tdx_bilinear_ac_fwd(const float* in, const float* scale, const float* shift,
+                        const float* addend, float* out,
+                        int B, int Hi, int Wi, int Ho, int Wo, int C,
+                        int out_cstride, int out_coff, tdx_stream_t stream);
+/* Transposed resize: g_in (B,Hi,Wi,C) from g_out slice (B,Ho,Wo,[coff:coff+C]). */
+int tdx_bilinear_ac_bwd(const float* g_out, float* g_in,
+                        int B, int Hi, int Wi, int Ho, int Wo, int C,
+                        int g_cstride, int g_coff, tdx_stream_t stream);
+
+/* ---- whole network ------------------------------------------------------ */
+
+/* Parameter slots, in reference state_dict order (diffusion.py:16-107).
+ * Conv/BN units: U0..U12 = enc1.0 enc1.3 enc2.0 enc2.3 enc3.0 enc3.3 bottleneck
+ *                          dec3.0 dec3.3 dec2.0 dec2.3 dec1.0 dec1.3 */
+enum {
+  TDX_P_TE0_W = 0, TDX_P_TE0_B, TDX_P_TE2_W, TDX_P_TE2_B,
+  TDX_P_CLASS_EMB,            /* NULL for the unconditional model */
+  TDX_P_INIT_W, TDX_P_INIT_B,
+  TDX_P_UNIT0,                /* 13 units x (conv_w, conv_b, bn_w, bn_b) */
+  TDX_P_FINAL_W = TDX_P_UNIT0 + 13 * 4, TDX_P_FINAL_B,
+  TDX_P_TP1_W, TDX_P_TP1_B, TDX_P_TP2_W, TDX_P_TP2_B, TDX_P_TP3_W, TDX_P_TP3_B,
+  TDX_P_COUNT
+};
+/* Buffer slots: 13 units x (running_mean, running_var, num_batches_tracked) */
+#define TDX_B_COUNT (13 * 3)
+
+#define TDX_MODE_TRAIN 0      /* batch statistics, activations saved for backward */
+#define TDX_MODE_EVAL_GRAD 1  /* running statistics, activations saved for backward */
+#define TDX_MODE_INFER 2      /* running statistics, fused conv+BN+ReLU, nothing saved */
+
+typedef struct tdx_unet tdx_unet;
+
+/* num_classes == 0: unconditional (diffusion.py); > 0: class-conditional. */
+int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes);
+int tdx_unet_destroy(tdx_unet* u);
+size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode);
+
+/* eps_hat = NoiseModel.forward(x, t[, y]) (diffusion.py:109-162).
+ *   params: TDX_P_COUNT device pointers (reference layout); buffers: TDX_B_COUNT.
+ *   x (B,1,28,28) fp32; t (B,) int64; y (B,) int64 or NULL; out (B,1,28,28).
+ * In TRAIN mode the BN running buffers are updated in place. */
+int tdx_unet_forward(tdx_unet* u, const void* const* params, void* const* buffers,
+                     const float* x, const int64_t* t, const int64_t* y, float* out,
+                     void* workspace, size_t workspace_bytes, int batch, int mode,
+                     tdx_stream_t stream);
+
+/* Gradients of every parameter for the most recent TRAIN/EVAL_GRAD forward on
+ * this plan+workspace (autograd of diffusion.py:235 through the UNet).
+ *   d_out (B,1,28,28); grads: TDX_P_COUNT device pointers, reference layout,
+ *   each fully overwritten (not accumulated).  stage_lo/stage_hi select a
+ *   contiguous range of backward stages [0, tdx_unet_backward_stages()) so the
+ *   host can all-reduce finished buckets while later stages run. */
+int tdx_unet_backward_stages(void);
+int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads,
+                      const float* d_out, void* workspace, size_t workspace_bytes,
+                      int batch, int stage_lo, int stage_hi, tdx_stream_t stream);
+
+/* Pack conv weights + fold nothing: refreshes the plan's device-side packed
+ * copies from `params`.  Called by forward automatically in TRAIN/EVAL_GRAD;
+ * INFER reuses the packed copy until this is called again. */
+int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const* buffers,
+                  tdx_stream_t stream);
+
+/* Peak probes used by bench.py for measured roofline denominators. */
+int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream);
+int tdx_probe_stream_copy(const float* src, float* dst, int64_t n, tdx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDX_H */

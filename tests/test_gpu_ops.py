@@ -1,0 +1,336 @@
+"""GPU parity of every libtdx building block against the CPU oracle
+(oracle/ref_cpu.py, itself pinned to the reference by tests/test_oracle_golden.py).
+All calls go through the C ABI (ctypes).  Tolerances: fp32, relative to the
+tensor's RMS; bit-exact where the arithmetic order is fixed."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def tdx():
+    import tiny_diffusion_amd._lib as L
+
+    assert torch.cuda.is_available()
+    return L
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_library_exports(tdx):
+    assert tdx.lib.tdx_version() == 100
+    maps = open("/proc/self/maps").read()
+    assert "libtdx.so" in maps
+
+
+def test_q_sample_bit_exact(tdx, golden_dir):
+    d = np.load(os.path.join(golden_dir, "fwd_B64_train_uncond.npz"))
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+
+    fp = ForwardProcess()
+    x_t, noise = fp.q_sample("cuda", torch.from_numpy(d["x0"]).cuda(), torch.from_numpy(d["t"]).cuda(),
+                             noise=torch.from_numpy(d["noise"]).cuda())
+    assert torch.equal(x_t.cpu(), torch.from_numpy(d["x_t"]))  # bit-exact vs the reference's own x_t
+    # schedule tables are the reference's
+    s = np.load(os.path.join(golden_dir, "schedule.npz"))
+    assert np.array_equal(fp.alphas_cumprod.numpy(), s["alphas_cumprod"])
+    sa, sb, coef = fp.tables("cuda")
+    assert np.array_equal(coef.cpu().numpy()[:, 0], s["c1"])
+    assert np.array_equal(coef.cpu().numpy()[:, 1], s["c2"])
+    assert np.array_equal(coef.cpu().numpy()[:, 2], s["sigma"])
+
+
+def test_q_sample_philox_statistics(tdx):
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+
+    fp = ForwardProcess()
+    B = 512
+    x0 = torch.zeros(B, 1, 28, 28, device="cuda")
+    t = torch.full((B,), 999, device="cuda")
+    x_t, noise = fp.q_sample_philox(x0, t, seed=7)
+    n = noise.double()
+    assert abs(n.mean().item()) < 0.01 and abs(n.std().item() - 1.0) < 0.01
+    assert abs((n**4).mean().item() - 3.0) < 0.1  # gaussian kurtosis
+    x2, n2 = fp.q_sample_philox(x0, t, seed=7)
+    assert torch.equal(n2, noise)  # counter-based: reproducible
+    x3, n3 = fp.q_sample_philox(x0, t, seed=8)
+    assert not torch.equal(n3, noise)
+    sa, sb, _ = fp.tables("cuda")
+    assert torch.equal(x_t, sb[999] * noise)
+
+
+@pytest.mark.parametrize("t", [999, 500, 1, 0])
+def test_p_sample_step_bit_exact(tdx, t):
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+    from tiny_diffusion_amd.schedule import p_sample_step
+
+    fp = ForwardProcess()
+    sched = R.Schedule()
+    g = torch.Generator().manual_seed(t)
+    x, eps, z = (torch.randn(16, 1, 28, 28, generator=g) for _ in range(3))
+    if t == 0:
+        z = torch.zeros_like(z)
+    ref = R.p_sample_step(sched, x, eps, t, z)
+    ti = torch.tensor([t], dtype=torch.int32, device="cuda")
+    got = p_sample_step(fp, x.cuda(), eps.cuda(), ti, None if t == 0 else z.cuda())
+    assert torch.equal(got.cpu(), ref)
+
+
+CONV_CASES = [
+    # B, H, cin, cout  (every (cin, cout, H) of the UNet + ragged M)
+    (4, 28, 64, 128), (2, 28, 128, 128), (3, 14, 128, 256), (3, 14, 256, 256), (5, 7, 256, 512),
+    (3, 7, 512, 512), (7, 4, 512, 512), (3, 8, 1024, 256), (3, 8, 256, 256), (2, 16, 512, 128),
+    (2, 16, 128, 128), (2, 32, 256, 64), (2, 32, 64, 64), (1, 7, 64, 64), (33, 28, 64, 128),
+]
+
+
+def _conv_inputs(B, H, cin, cout, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    return x, w, b
+
+
+def _pack(tdx, w):
+    cout, cin = w.shape[:2]
+    wd = dev(w)
+    wf = torch.empty(cout * 9 * cin, device="cuda")
+    wg = torch.empty(cout * 9 * cin, device="cuda")
+    tdx.check(tdx.lib.tdx_pack_conv3x3(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), cout, cin, stream()))
+    return wf, wg
+
+
+@pytest.mark.parametrize("B,H,cin,cout", CONV_CASES)
+def test_conv3x3_fwd_plain_and_stats(tdx, B, H, cin, cout):
+    x, w, b = _conv_inputs(B, H, cin, cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    wf, _ = _pack(tdx, w)
+    xin = dev(nhwc(x))
+    out = torch.full((B, H, H, cout), float("nan"), device="cuda")
+    tiles = tdx.lib.tdx_conv3x3_stat_tiles(B, H, H, cin, cout)
+    stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd(xin.data_ptr(), wf.data_ptr(), dev(b).data_ptr(), out.data_ptr(), B, H, H,
+                                      cin, cout, 4, None, None, None, None, stats.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref) < 2e-6
+    s = stats.double().sum(0).cpu()
+    assert torch.allclose(s[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s[1], ref.double().pow(2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 14, 128, 256), (2, 32, 64, 64), (5, 7, 512, 512)])
+def test_conv3x3_fwd_fused_bn_relu(tdx, B, H, cin, cout):
+    """input BN+ReLU on load and output BN+ReLU epilogue (inference path)."""
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=1)
+    g = torch.Generator().manual_seed(5)
+    isc, ish = torch.randn(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    osc, osh = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.3
+    a = F.relu(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+    ref = F.relu(F.conv2d(a, w, b, padding=1) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
+    wf, _ = _pack(tdx, w)
+    out = torch.empty((B, H, H, cout), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd(dev(nhwc(x)).data_ptr(), wf.data_ptr(), dev(b).data_ptr(), out.data_ptr(),
+                                      B, H, H, cin, cout, 1 | 2, dev(isc).data_ptr(), dev(ish).data_ptr(),
+                                      dev(osc).data_ptr(), dev(osh).data_ptr(), None, stream()))
+    assert rel_err(nchw(out), ref) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,cin,cout", CONV_CASES)
+def test_conv3x3_dgrad_and_wgrad(tdx, B, H, cin, cout):
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=2)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+    y.backward(g)
+    _, wd = _pack(tdx, w.detach())
+    gd = dev(nhwc(g))
+    gin = torch.empty((B, H, H, cin), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd(gd.data_ptr(), wd.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                      None, None, None, None, None, stream()))
+    assert rel_err(nchw(gin), x.grad) < 2e-6
+    splits = tdx.lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_wgrad(dev(nhwc(x.detach())).data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H,
+                                        cin, cout, 0, None, None, stream()))
+    tdx.check(tdx.lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, stream()))
+    assert rel_err(dw, w.grad) < 3e-6
+
+
+def test_conv3x3_wgrad_bnrelu_input(tdx):
+    B, H, cin, cout = 3, 14, 128, 256
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=4)
+    g = torch.Generator().manual_seed(6)
+    isc, ish = torch.randn(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    a = F.relu(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+    w.requires_grad_(True)
+    y = F.conv2d(a, w, b, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    splits = tdx.lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    slabs = torch.empty((splits, cout, 9, cin), device="cuda")
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_wgrad(dev(nhwc(x)).data_ptr(), dev(nhwc(gy)).data_ptr(), slabs.data_ptr(), B, H, H,
+                                        cin, cout, 1, dev(isc).data_ptr(), dev(ish).data_ptr(), stream()))
+    tdx.check(tdx.lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, stream()))
+    assert rel_err(dw, w.grad) < 3e-6
+
+
+@pytest.mark.parametrize("training", [1, 0])
+def test_bn_finalize_and_backward(tdx, training):
+    """BatchNorm2d train/eval forward statistics + BN/ReLU backward vs autograd."""
+    B, H, Cc = 6, 14, 128
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(B, Cc, H, H, generator=g) * 2 + 0.5
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(Cc, generator=g)).requires_grad_(True)
+    rm, rv = torch.randn(Cc, generator=g) * 0.1, 1 + torch.rand(Cc, generator=g)
+    nbt = torch.tensor(3)
+    yy = y.clone().requires_grad_(True)
+    rm_ref, rv_ref, nbt_ref = rm.clone(), rv.clone(), nbt.clone()
+    a = F.relu(R.batchnorm2d(yy, gamma, beta, rm_ref, rv_ref, bool(training), nbt_ref))
+    ga = torch.randn(a.shape, generator=g)
+    a.backward(ga)
+    # ---- device
+    yd = dev(nhwc(y))
+    rows = B * H * H
+    # emulate the conv epilogue partials with 3 uneven tiles
+    cuts = [0, 100, 700, rows]
+    y2 = yd.view(rows, Cc).double()
+    stats = torch.stack([torch.stack([y2[cuts[i]:cuts[i + 1]].sum(0), y2[cuts[i]:cuts[i + 1]].pow(2).sum(0)])
+                         for i in range(3)]).float().contiguous()
+    sc, sh, mu, rs = (torch.empty(Cc, device="cuda") for _ in range(4))
+    rmd, rvd, nbtd = dev(rm), dev(rv), nbt.cuda()
+    tdx.check(tdx.lib.tdx_bn_finalize(stats.data_ptr(), 3, rows, Cc, dev(gamma.detach()).data_ptr(),
+                                      dev(beta.detach()).data_ptr(), rmd.data_ptr(), rvd.data_ptr(), nbtd.data_ptr(),
+                                      sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), training, stream()))
+    act = F.relu(yd * sc + sh)
+    assert rel_err(nchw(act), a.detach()) < 2e-6
+    if training:
+        assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+        assert int(nbtd) == int(nbt_ref) == 4
+    else:
+        assert torch.equal(rmd.cpu(), rm) and int(nbtd) == 3
+    gd = dev(nhwc(ga))
+    n_scr = tdx.lib.tdx_bn_relu_bwd_scratch_floats(rows, Cc)
+    scr = torch.empty(n_scr, device="cuda")
+    dg, db, dbias = (torch.empty(Cc, device="cuda") for _ in range(3))
+    tdx.check(tdx.lib.tdx_bn_relu_bwd(gd.data_ptr(), yd.data_ptr(), rows, Cc, sc.data_ptr(), sh.data_ptr(),
+                                      mu.data_ptr(), rs.data_ptr(), dev(gamma.detach()).data_ptr(), dg.data_ptr(),
+                                      db.data_ptr(), dbias.data_ptr(), scr.data_ptr(), training, stream()))
+    assert rel_err(nchw(gd), yy.grad) < 5e-6
+    assert rel_err(dg, gamma.grad) < 5e-6
+    assert rel_err(db, beta.grad) < 5e-6
+    ref_dbias = yy.grad.sum((0, 2, 3))
+    if training:
+        assert dbias.abs().max().item() == 0.0 and ref_dbias.abs().max().item() < 1e-3
+    else:
+        assert rel_err(dbias, ref_dbias) < 5e-6
+
+
+@pytest.mark.parametrize("H,Cc", [(28, 128), (14, 256), (7, 512), (5, 64)])
+def test_maxpool_ceil_fwd_bwd(tdx, H, Cc):
+    B = 3
+    g = torch.Generator().manual_seed(H)
+    y = torch.randn(B, Cc, H, H, generator=g)
+    sc, sh = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g) * 0.2
+    a = F.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    ref = R.maxpool2_ceil(a)
+    assert torch.equal(ref, F.max_pool2d(a, 2, ceil_mode=True))
+    Ho = (H + 1) // 2
+    yd = dev(nhwc(y))
+    out = torch.empty((B, Ho, Ho, Cc), device="cuda")
+    tdx.check(tdx.lib.tdx_maxpool2_ceil_fwd(yd.data_ptr(), dev(sc).data_ptr(), dev(sh).data_ptr(), out.data_ptr(),
+                                            B, H, H, Cc, stream()))
+    assert rel_err(nchw(out), ref.detach()) < 1e-6
+    go = torch.randn(ref.shape, generator=g)
+    skip = torch.randn(a.shape, generator=g)
+    # many exact ties (zeros after ReLU): torch routes to the first maximum
+    F.max_pool2d(a, 2, ceil_mode=True).backward(go)
+    gin = torch.empty((B, H, H, Cc), device="cuda")
+    tdx.check(tdx.lib.tdx_maxpool2_ceil_bwd(yd.data_ptr(), dev(sc).data_ptr(), dev(sh).data_ptr(),
+                                            dev(nhwc(go)).data_ptr(), dev(nhwc(skip)).data_ptr(), gin.data_ptr(),
+                                            B, H, H, Cc, stream()))
+    assert torch.allclose(nchw(gin).cpu(), a.grad + skip, rtol=1e-6, atol=1e-6)
+
+
+RESIZES = [(4, 8, 512), (7, 8, 512), (8, 16, 256), (14, 16, 256), (16, 32, 128), (28, 32, 128), (32, 28, 64)]
+
+
+@pytest.mark.parametrize("hi,ho,Cc", RESIZES)
+def test_bilinear_align_corners_fwd_bwd(tdx, hi, ho, Cc):
+    """The 7 resizes of the UNet (diffusion.py:135-159), with BN+ReLU on load,
+    broadcast addend and channel-slice destination."""
+    B = 2
+    g = torch.Generator().manual_seed(hi * 100 + ho)
+    y = torch.randn(B, Cc, hi, hi, generator=g)
+    sc, sh = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g) * 0.2
+    add = torch.randn(B, Cc, generator=g)
+    a = (F.relu(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + add.view(B, Cc, 1, 1)).requires_grad_(True)
+    ref = F.interpolate(a, size=(ho, ho), mode="bilinear", align_corners=True)
+    assert rel_err(R.bilinear_ac(a.detach(), (ho, ho)), ref.detach()) < 1e-7
+    cs, co = 2 * Cc, Cc  # write into the upper channel half of a wider buffer
+    out = torch.zeros((B, ho, ho, cs), device="cuda")
+    tdx.check(tdx.lib.tdx_bilinear_ac_fwd(dev(nhwc(y)).data_ptr(), dev(sc).data_ptr(), dev(sh).data_ptr(),
+                                          dev(add).data_ptr(), out.data_ptr(), B, hi, hi, ho, ho, Cc, cs, co, stream()))
+    assert rel_err(nchw(out[..., co:]), ref.detach()) < 1e-6
+    assert out[..., :co].abs().max().item() == 0.0
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    gbuf = torch.zeros((B, ho, ho, cs), device="cuda")
+    gbuf[..., co:] = dev(nhwc(go))
+    gin = torch.empty((B, hi, hi, Cc), device="cuda")
+    tdx.check(tdx.lib.tdx_bilinear_ac_bwd(gbuf.data_ptr(), gin.data_ptr(), B, hi, hi, ho, ho, Cc, cs, co, stream()))
+    assert rel_err(nchw(gin), a.grad) < 2e-6
+
+
+def test_mse_and_adam(tdx):
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(64, 784, generator=g), torch.randn(64, 784, generator=g)
+    ar = a.clone().requires_grad_(True)
+    loss = F.mse_loss(ar, b); loss.backward()
+    lo, da = torch.empty(1, device="cuda"), torch.empty(a.shape, device="cuda")
+    tdx.check(tdx.lib.tdx_mse_loss(dev(a).data_ptr(), dev(b).data_ptr(), lo.data_ptr(), da.data_ptr(), 1.0,
+                                   a.numel(), stream()))
+    assert abs(lo.item() - loss.item()) < 1e-6 * loss.item()
+    assert rel_err(da, ar.grad) < 1e-6
+    # Adam vs torch.optim.Adam, 3 steps
+    p = torch.randn(10000, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd, m, v = dev(p), torch.zeros(10000, device="cuda"), torch.zeros(10000, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(10000, generator=g)
+        pr.grad = gr.clone(); opt.step()
+        tdx.check(tdx.lib.tdx_adam_step(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), 10000,
+                                        1e-3, 0.9, 0.999, 1e-8, step, 1.0, stream()))
+    assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6

@@ -1,0 +1,128 @@
+"""ctypes binding of libtdx.so (include/tdx.h).
+
+There is no CPU fallback: if the library is missing or fails to load, importing
+this module raises.  The library is linked against ``libamdhip64.so.7``; torch is
+imported first so that the HIP runtime torch already mapped (same SONAME) is
+the one libtdx binds to - streams and device pointers are then shared.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+from . import _build
+
+_c_float_p = C.c_void_p
+_c_i64_p = C.c_void_p
+_ptr = C.c_void_p
+
+
+class TdxError(RuntimeError):
+    pass
+
+
+def _load():
+    path = _build.LIB
+    if not os.path.exists(path):
+        if os.environ.get("TDX_NO_AUTOBUILD"):
+            raise TdxError(
+                f"{path} not found: build it with `python -m tiny_diffusion_amd._build` "
+                "(there is no CPU fallback for the HIP path)"
+            )
+        _build.build()
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # one HIP runtime per process, or streams/pointers would not be shared
+    hips = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    hips.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    if len(hips) > 1:
+        raise TdxError(f"two HIP runtimes mapped in one process: {sorted(hips)}")
+    return lib
+
+
+lib = _load()
+
+_SIGS = {
+    "tdx_version": (C.c_int, []),
+    "tdx_error_string": (C.c_char_p, [C.c_int]),
+    "tdx_q_sample": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_q_sample_philox": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int,
+                                      C.c_uint64, C.c_uint64, _ptr]),
+    "tdx_p_sample_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr]),
+    "tdx_p_sample_step_philox": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_uint64, _ptr]),
+    "tdx_mse_loss": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_float, C.c_int64, _ptr]),
+    "tdx_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int, C.c_float, _ptr]),
+    "tdx_pack_conv3x3": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_conv3x3_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_wgrad": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, _ptr, _ptr, _ptr]),
+    "tdx_conv3x3_wgrad_reduce": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_bn_finalize": (C.c_int, [_ptr, C.c_int, C.c_int64, C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                  _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
+    "tdx_bn_relu_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                  _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
+    "tdx_bn_relu_bwd_scratch_floats": (C.c_size_t, [C.c_int64, C.c_int]),
+    "tdx_maxpool2_ceil_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_maxpool2_ceil_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, _ptr]),
+    "tdx_bilinear_ac_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_bilinear_ac_bwd": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, _ptr]),
+    "tdx_unet_create": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int]),
+    "tdx_unet_destroy": (C.c_int, [_ptr]),
+    "tdx_unet_workspace_bytes": (C.c_size_t, [_ptr, C.c_int, C.c_int]),
+    "tdx_unet_forward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int,
+                                   C.c_int, _ptr]),
+    "tdx_unet_backward_stages": (C.c_int, []),
+    "tdx_unet_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                    _ptr]),
+    "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
+    "tdx_probe_mfma_f32": (C.c_int, [_ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_probe_stream_copy": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def _bind():
+    missing = []
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise TdxError(f"libtdx.so lacks symbols declared in include/tdx.h: {missing}")
+
+
+_bind()
+
+
+def check(code: int, what: str = "tdx"):
+    if code != 0:
+        msg = lib.tdx_error_string(code)
+        raise TdxError(f"{what} failed: {msg.decode() if msg else code} ({code})")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream

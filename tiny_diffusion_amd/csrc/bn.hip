@@ -1,0 +1,217 @@
+// BatchNorm2d (+ReLU) around the MFMA convolutions (diffusion.py:34 and siblings).
+//
+// Forward: the convolution epilogue leaves per-tile (sum, sumsq) partials; this
+// file turns them into per-channel scale/shift that CONSUMERS apply on load
+// (relu(y*scale+shift)), so the normalised activation is never written to HBM.
+// Backward: two per-channel reductions over (g, y), then one in-place pass.
+#include "common.h"
+
+#define BN_EPS 1e-5f
+#define BN_MOMENTUM 0.1f
+
+// block = 256 threads = 32 channels x 8 slices of the tile list; double accumulation
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ stats, int tiles, double count, int C,
+                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                   float* __restrict__ rmean, float* __restrict__ rvar,
+                   int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
+                   float* __restrict__ save_mean, float* __restrict__ save_rstd, int training) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    if (c < C)
+      for (int t = sl; t < tiles; t += 8) {
+        s += (double)stats[((size_t)t * 2 + 0) * C + c];
+        q += (double)stats[((size_t)t * 2 + 1) * C + c];
+      }
+    red[0][sl][cl] = s;
+    red[1][sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      s = 0.0; q = 0.0;
+      for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+      const double mean = s / count;
+      double var = q / count - mean * mean;  // biased, used to normalise
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+      const float sc = gamma[c] * rstd;
+      scale[c] = sc;
+      shift[c] = beta[c] - (float)mean * sc;
+      if (save_mean) save_mean[c] = (float)mean;
+      if (save_rstd) save_rstd[c] = rstd;
+      if (rmean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.0f - BN_MOMENTUM) * rmean[c] + BN_MOMENTUM * (float)mean;
+        rvar[c] = (1.0f - BN_MOMENTUM) * rvar[c] + BN_MOMENTUM * (float)unbiased;
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  } else if (sl == 0 && c < C) {
+    const float mean = rmean[c];
+    const float rstd = 1.0f / sqrtf(rvar[c] + BN_EPS);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_rstd) save_rstd[c] = rstd;
+  }
+}
+
+extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int64_t count, int C,
+                               const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* scale,
+                               float* shift, float* save_mean, float* save_rstd, int training,
+                               tdx_stream_t stream) {
+  if (!gamma || !beta || !scale || !shift || C <= 0) return TDX_E_BADARG;
+  if (training && (!stats_partial || tiles <= 0 || count <= 0)) return TDX_E_BADARG;
+  if (!training && (!running_mean || !running_var)) return TDX_E_BADARG;
+  bn_finalize_kernel<<<cdiv(C, 32), 256, 0, to_stream(stream)>>>(
+      stats_partial, tiles, (double)count, C, gamma, beta, running_mean, running_var,
+      num_batches_tracked, scale, shift, save_mean, save_rstd, training);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ backward
+#define BWD_ROWS 512  // rows per block in the reduction pass
+
+// partial[blk][2][C]: sum gz, sum gz*xhat over the block's rows
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t rows, int C,
+                     const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                     float* __restrict__ partial) {
+  extern __shared__ float red[];  // [rgroups][2][C]
+  const int c4n = C / 4;
+  const int col = threadIdx.x % c4n, rg = threadIdx.x / c4n, rgroups = 256 / c4n;
+  const int c = col * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+  const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
+  const int64_t r1 = min(r0 + BWD_ROWS, rows);
+  for (int64_t r = r0 + rg; r < r1; r += rgroups) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + r * C + c);
+    const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+#define ACC(k)                                                   \
+    {                                                            \
+      const float gz = fmaf(yv.k, sc.k, sh.k) > 0.f ? gv.k : 0.f; \
+      s1.k += gz;                                                \
+      s2.k += gz * ((yv.k - mu.k) * rs.k);                       \
+    }
+    ACC(x) ACC(y) ACC(z) ACC(w)
+#undef ACC
+  }
+  *reinterpret_cast<float4*>(red + (rg * 2 + 0) * C + c) = s1;
+  *reinterpret_cast<float4*>(red + (rg * 2 + 1) * C + c) = s2;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < rgroups; ++k) v += red[k * 2 * C + i];
+    partial[(size_t)blockIdx.x * 2 * C + i] = v;
+  }
+}
+
+// coef[5][C]: k1 = gamma*rstd (train) or scale (eval), m1 = S1/N, m2 = S2/N
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count, int C,
+                       const float* __restrict__ gamma, const float* __restrict__ rstd,
+                       const float* __restrict__ scale, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta, float* __restrict__ dbias,
+                       float* __restrict__ coef, int training) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int t = sl; t < nblk; t += 8) {
+      s1 += (double)partial[((size_t)t * 2 + 0) * C + c];
+      s2 += (double)partial[((size_t)t * 2 + 1) * C + c];
+    }
+  red[0][sl][cl] = s1;
+  red[1][sl][cl] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    s1 = 0.0; s2 = 0.0;
+    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    if (training) {
+      coef[0 * C + c] = gamma[c] * rstd[c];
+      coef[1 * C + c] = (float)(s1 / count);
+      coef[2 * C + c] = (float)(s2 / count);
+      // d(conv bias) = sum over rows of dy == 0 analytically: the batch mean removes it
+      if (dbias) dbias[c] = 0.f;
+    } else {
+      coef[0 * C + c] = scale[c];
+      coef[1 * C + c] = 0.f;
+      coef[2 * C + c] = 0.f;
+      if (dbias) dbias[c] = (float)(s1 * (double)scale[c]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t n4, int C,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                    const float* __restrict__ coef) {
+  const int c4n = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+    const float4 m1 = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 m2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    float4 gv = reinterpret_cast<float4*>(g)[i];
+    const float4 yv = reinterpret_cast<const float4*>(y)[i];
+#define APPLY(k)                                                     \
+    {                                                                \
+      const float gz = fmaf(yv.k, sc.k, sh.k) > 0.f ? gv.k : 0.f;    \
+      const float xh = (yv.k - mu.k) * rs.k;                         \
+      gv.k = k1.k * (gz - m1.k - xh * m2.k);                         \
+    }
+    APPLY(x) APPLY(y) APPLY(z) APPLY(w)
+#undef APPLY
+    reinterpret_cast<float4*>(g)[i] = gv;
+  }
+}
+
+extern "C" size_t tdx_bn_relu_bwd_scratch_floats(int64_t rows, int C) {
+  return (size_t)cdiv(rows, BWD_ROWS) * 2 * C + 3 * (size_t)C;
+}
+
+extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, const float* scale,
+                               const float* shift, const float* save_mean, const float* save_rstd,
+                               const float* gamma, float* dgamma, float* dbeta, float* dbias,
+                               float* scratch, int training, tdx_stream_t stream) {
+  if (!g || !y || !scale || !shift || !save_mean || !save_rstd || !gamma || !scratch || rows <= 0)
+    return TDX_E_BADARG;
+  if (C % 4 || C > 1024 || (256 % (C / 4)) != 0) return TDX_E_SHAPE;
+  hipStream_t st = to_stream(stream);
+  const int nblk = cdiv(rows, BWD_ROWS);
+  float* partial = scratch;
+  float* coef = scratch + (size_t)nblk * 2 * C;
+  const int rgroups = 256 / (C / 4);
+  bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
+      g, y, rows, C, scale, shift, save_mean, save_rstd, partial);
+  TDX_CHECK_LAUNCH();
+  bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
+                                                     save_rstd, scale, dgamma, dbeta, dbias, coef,
+                                                     training);
+  TDX_CHECK_LAUNCH();
+  const int64_t n4 = rows * C / 4;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(g, y, n4, C, scale, shift, save_mean, save_rstd, coef);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}

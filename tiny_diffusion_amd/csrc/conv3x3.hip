@@ -1,0 +1,556 @@
+// 3x3 / pad 1 / stride 1 convolution on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), channels-last.
+//
+// Replaces every nn.Conv2d(cin, cout, 3, padding=1) with cin >= 64 of the
+// reference UNet (diffusion.py:32-95) - >= 99.9 % of its FLOPs - in three roles:
+//   forward   out[p][co]   = sum_{tap,ci} in[p+tap][ci] * W[co][tap][ci]
+//   dgrad     same kernel on the flipped/transposed pack of W
+//   wgrad     dW[co][tap][ci] = sum_p dy[p][co] * in[p+tap][ci]   (split over p)
+//
+// Implicit GEMM, no im2col buffer: a K-tile is 32 input channels of ONE tap, so
+// an A-tile row is 128 contiguous bytes of the NHWC input (or zeros for padding).
+// Tiles are staged global -> registers -> LDS (double-buffered, the loads of tile
+// k+1 are issued before the MFMAs of tile k and written after them), rows padded
+// to 36 floats so that the ds_read_b128 fragment reads are bank-conflict-free.
+//
+// MFMA operand trick: lane l supplies A[i=l&31][k=l>>5].  Each lane reads FOUR
+// consecutive k of its row with one ds_read_b128 (lanes 0-31 take k..k+3, lanes
+// 32-63 take k+4..k+7) and issues four MFMAs from it; A and B use the same
+// permutation of k, so the sum over k is unchanged.
+#include "common.h"
+
+#define BK 32   // K-tile: 32 channels of one tap
+#define BKP 36  // padded LDS row (floats)
+
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BNRELU = 2 };
+
+struct ConvArgs {
+  const float* in;
+  const float* w;  // [Cout][9][Cin]
+  const float* bias;
+  float* out;
+  const float* in_scale;
+  const float* in_shift;
+  const float* out_scale;
+  const float* out_shift;
+  float* stats;  // [tilesM][2][Cout]
+  int B, H, W, Cin, Cout, M, tilesN;
+};
+
+template <int BM, int BN, bool IN_BN, int EPI>
+__global__ void __launch_bounds__(256)
+conv3x3_igemm_kernel(ConvArgs a) {
+  constexpr int WGM = 2, WGN = 2;  // 4 waves as 2 x 2
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;  // float4 loads per thread per K-tile
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][BKP]
+  float* Bs = smem + 2 * BM * BKP;  // [2][BN][BKP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W;
+
+  // ---- per-thread A rows: pixel coordinates (fixed across the K loop)
+  const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
+  int a_pix[AI], a_oh[AI], a_ow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int p = m0 + ld_row + 32 * i;
+    if (p < a.M) {
+      int r = p % HW;
+      a_pix[i] = p;
+      a_oh[i] = r / a.W;
+      a_ow[i] = r % a.W;
+    } else {
+      a_pix[i] = 0;
+      a_oh[i] = -100000;  // fails every bounds test
+      a_ow[i] = 0;
+    }
+  }
+  const float* wrow[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j)
+    wrow[j] = a.w + (size_t)(n0 + ld_row + 32 * j) * (9 * a.Cin) + ld_c4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  const int nk = 9 * (a.Cin / BK);
+  float4 ra[AI], rb[BI];
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // Software pipeline without conditionals on the staging registers: iteration kt
+  // issues the global loads of tile kt+1 (clamped: the last iteration re-loads the
+  // last tile and stores it into the idle buffer, which nobody reads), runs the
+  // MFMAs of tile kt from LDS, then writes the staged registers.  kt = -1 is the
+  // prologue (loads tile 0, no MFMAs).
+  int cur = 1;
+  for (int kt = -1; kt < nk; ++kt) {
+    {
+      const int kn = min(kt + 1, nk - 1);
+      const int cblk = kn / 9, tap = kn - cblk * 9;
+      const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
+      const int c0 = cblk * BK + ld_c4;
+      if (IN_BN) {
+        sc4 = *reinterpret_cast<const float4*>(a.in_scale + c0);
+        sh4 = *reinterpret_cast<const float4*>(a.in_shift + c0);
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
+        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+          v = *reinterpret_cast<const float4*>(a.in + (size_t)(a_pix[i] + dh * a.W + dw) * a.Cin + c0);
+          if (IN_BN) {
+            v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
+            v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
+            v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+          }
+        }
+        ra[i] = v;
+      }
+      const int koff = tap * a.Cin + cblk * BK;
+#pragma unroll
+      for (int j = 0; j < BI; ++j) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + koff);
+    }
+    if (kt >= 0) {
+      const float* Ab = As + cur * BM * BKP + (wm * WTM + l31) * BKP + half * 4;
+      const float* Bb = Bs + cur * BN * BKP + (wn * WTN + l31) * BKP + half * 4;
+#pragma unroll
+      for (int ks = 0; ks < BK / 8; ++ks) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+          af[im] = *reinterpret_cast<const f32x4*>(Ab + im * 32 * BKP + ks * 8);
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          bf[in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BKP + ks * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] =
+                  __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+      }
+    }
+    {
+      float* Ab = As + (cur ^ 1) * BM * BKP;
+      float* Bb = Bs + (cur ^ 1) * BN * BKP;
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        *reinterpret_cast<float4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = ra[i];
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        *reinterpret_cast<float4*>(Bb + (ld_row + 32 * j) * BKP + ld_c4) = rb[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
+  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int col = n0 + wn * WTN + in * 32 + l31;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float osc = 1.f, osh = 0.f;
+    if (EPI == EPI_BNRELU) {
+      osc = a.out_scale[col];
+      osh = a.out_shift[col];
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int p = m0 + row;
+        float v = acc[im][in][r] + bv;
+        if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
+        if (p < a.M) {
+          a.out[(size_t)p * a.Cout + col] = v;
+          s += v;
+          q += v * v;
+        }
+      }
+    }
+    csum[in] = s;
+    csq[in] = q;
+  }
+  if (EPI == EPI_STATS) {
+    // column sums: lane halves -> waves sharing the column range -> one row of partials
+    float* red = smem;  // [WGM][2][BN], re-uses the tile buffers (all waves are past the K loop)
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      float s = csum[in] + __shfl_xor(csum[in], 32, 64);
+      float q = csq[in] + __shfl_xor(csq[in], 32, 64);
+      if (half == 0) {
+        red[(wm * 2 + 0) * BN + wn * WTN + in * 32 + l31] = s;
+        red[(wm * 2 + 1) * BN + wn * WTN + in * 32 + l31] = q;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, c = i - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[(w * 2 + which) * BN + c];
+      a.stats[((size_t)tile_m * 2 + which) * a.Cout + n0 + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dispatch
+struct TileCfg {
+  int bm, bn;
+};
+
+static TileCfg pick_tile(int64_t M, int cout) {
+  const TileCfg cands[3] = {{128, 128}, {128, 64}, {64, 64}};
+  for (int i = 0; i < 3; ++i) {
+    if (cout % cands[i].bn) continue;
+    int64_t tiles = ((M + cands[i].bm - 1) / cands[i].bm) * (cout / cands[i].bn);
+    if (tiles >= 448 || i == 2) return cands[i];
+  }
+  return cands[2];
+}
+
+template <int BM, int BN>
+static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
+  const int grid = cdiv(a.M, BM) * a.tilesN;
+  const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+  const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU
+                  : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS
+                                                 : EPI_PLAIN;
+#define TDX_LAUNCH(INBN, EPI_)                                                              \
+  do {                                                                                      \
+    auto kern = conv3x3_igemm_kernel<BM, BN, INBN, EPI_>;                                   \
+    static bool attr_set = false;                                                           \
+    if (lds > 65536 && !attr_set) {                                                         \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                   \
+      attr_set = true;                                                                      \
+    }                                                                                       \
+    kern<<<grid, 256, lds, st>>>(a);                                                        \
+  } while (0)
+  if (in_bn) {
+    if (epi == EPI_BNRELU) TDX_LAUNCH(true, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH(true, EPI_STATS);
+    else TDX_LAUNCH(true, EPI_PLAIN);
+  } else {
+    if (epi == EPI_BNRELU) TDX_LAUNCH(false, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH(false, EPI_STATS);
+    else TDX_LAUNCH(false, EPI_PLAIN);
+  }
+#undef TDX_LAUNCH
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout) {
+  (void)cin;
+  int64_t M = (int64_t)B * H * W;
+  return cdiv(M, pick_tile(M, cout).bm);
+}
+
+extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,
+                               int B, int H, int W, int cin, int cout, int flags,
+                               const float* in_scale, const float* in_shift,
+                               const float* out_scale, const float* out_shift,
+                               float* stats_partial, tdx_stream_t stream) {
+  if (!in || !wpk || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  if (cin % BK || cout % 64) return TDX_E_SHAPE;
+  if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_BNRELU) && (!out_scale || !out_shift)) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_STATS) && !stats_partial) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_STATS) && (flags & TDX_CONV_OUT_BNRELU)) return TDX_E_BADARG;
+  int64_t M64 = (int64_t)B * H * W;
+  if (M64 >= (1ll << 31)) return TDX_E_SHAPE;
+  ConvArgs a;
+  a.in = in; a.w = wpk; a.bias = bias; a.out = out;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
+  a.stats = stats_partial;
+  a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
+  TileCfg c = pick_tile(M64, cout);
+  a.tilesN = cout / c.bn;
+  hipStream_t st = to_stream(stream);
+  if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128>(a, flags, st);
+  if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64>(a, flags, st);
+  return launch_conv<64, 64>(a, flags, st);
+}
+
+// ---------------------------------------------------------------------- wgrad
+// GEMM: rows = output channels, cols = input channels of ONE tap, K = pixels.
+// Both operands are k-major in memory ([pixel][channel]), so LDS tiles are
+// [32 pixels][channels] and a lane reads TM (TN) adjacent channels of its pixel
+// row: MFMA tile `im` then holds channels  base + TM*i + im  (i = MFMA row), a
+// permutation that the epilogue undoes.
+struct WgradArgs {
+  const float* in;  // (B,H,W,Cin)
+  const float* dy;  // (B,H,W,Cout)
+  float* slabs;     // [S][Cout][9][Cin]
+  const float* in_scale;
+  const float* in_shift;
+  int B, H, W, Cin, Cout, M, tilesCi, chunk;
+};
+
+template <int BM, int BN, bool IN_BN>
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ACH = BM / 4, BCH = BN / 4;          // float4 chunks per pixel row
+  constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;  // pixel rows per pass
+  constexpr int AI = 32 / AROWS, BI = 32 / BROWS;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][32][BM]
+  float* Bs = smem + 2 * 32 * BM;  // [2][32][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  int t = blockIdx.x;
+  const int tile_ci = t % a.tilesCi; t /= a.tilesCi;
+  const int tap = t % 9;
+  const int tile_co = t / 9;
+  const int co0 = tile_co * BM, ci0 = tile_ci * BN;
+  const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+  const int HW = a.H * a.W;
+  const int p_lo = blockIdx.y * a.chunk;
+  const int p_hi = min(p_lo + a.chunk, a.M);
+
+  const int a_c4 = (tid % ACH) * 4, a_r0 = tid / ACH;
+  const int b_c4 = (tid % BCH) * 4, b_r0 = tid / BCH;
+  float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (IN_BN) {
+    sc4 = *reinterpret_cast<const float4*>(a.in_scale + ci0 + b_c4);
+    sh4 = *reinterpret_cast<const float4*>(a.in_shift + ci0 + b_c4);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  float4 ra[AI], rb[BI];
+  const int nk = (p_hi - p_lo + 31) / 32;
+  int cur = 1;
+  for (int kt = -1; kt < nk; ++kt) {  // same register-staged pipeline as the forward kernel
+    {
+      const int pbase = p_lo + min(kt + 1, nk - 1) * 32;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int p = pbase + a_r0 + AROWS * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < p_hi) v = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.Cout + co0 + a_c4);
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const int p = pbase + b_r0 + BROWS * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < p_hi) {
+          const int r = p % HW;
+          const int ih = r / a.W + dh, iw = r % a.W + dw;
+          if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+            v = *reinterpret_cast<const float4*>(a.in + (size_t)(p + dh * a.W + dw) * a.Cin + ci0 + b_c4);
+            if (IN_BN) {
+              v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
+              v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+              v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
+              v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+            }
+          }
+        }
+        rb[i] = v;
+      }
+    }
+    if (kt >= 0) {
+      const float* Ab = As + cur * 32 * BM + half * BM + wm * WTM + TM * l31;
+      const float* Bb = Bs + cur * 32 * BN + half * BN + wn * WTN + TN * l31;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        float af[TM], bf[TN];
+        if (TM == 2) {
+          float2 v = *reinterpret_cast<const float2*>(Ab + ks * 2 * BM);
+          af[0] = v.x; af[TM - 1] = v.y;
+        } else {
+          af[0] = Ab[ks * 2 * BM];
+        }
+        if (TN == 2) {
+          float2 v = *reinterpret_cast<const float2*>(Bb + ks * 2 * BN);
+          bf[0] = v.x; bf[TN - 1] = v.y;
+        } else {
+          bf[0] = Bb[ks * 2 * BN];
+        }
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im], bf[in], acc[im][in], 0, 0, 0);
+      }
+    }
+    {
+      float* Ab = As + (cur ^ 1) * 32 * BM;
+      float* Bb = Bs + (cur ^ 1) * 32 * BN;
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        *reinterpret_cast<float4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BI; ++i)
+        *reinterpret_cast<float4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = rb[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* slab = a.slabs + (size_t)blockIdx.y * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + wm * WTM + TM * i + im;
+        const int ci = ci0 + wn * WTN + TN * l31 + in;
+        slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[im][in][r];
+      }
+}
+
+struct WgradCfg {
+  int bm, bn, splits, chunk;
+};
+
+static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
+  WgradCfg c;
+  c.bm = (cout % 128 == 0) ? 128 : 64;
+  c.bn = (cin % 128 == 0) ? 128 : 64;
+  int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
+  int64_t s = (1024 + tiles - 1) / tiles;
+  int64_t smax = (M + 255) / 256;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  int64_t chunk = (M + s - 1) / s;
+  chunk = (chunk + 31) / 32 * 32;
+  s = (M + chunk - 1) / chunk;
+  c.splits = (int)s;
+  c.chunk = (int)chunk;
+  return c;
+}
+
+extern "C" int tdx_conv3x3_wgrad_splits(int B, int H, int W, int cin, int cout) {
+  return pick_wgrad((int64_t)B * H * W, cin, cout).splits;
+}
+
+template <int BM, int BN>
+static int launch_wgrad(const WgradArgs& a, int splits, bool in_bn, hipStream_t st) {
+  const size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
+  dim3 grid((a.Cout / BM) * 9 * a.tilesCi, splits);
+  if (in_bn) conv3x3_wgrad_kernel<BM, BN, true><<<grid, 256, lds, st>>>(a);
+  else conv3x3_wgrad_kernel<BM, BN, false><<<grid, 256, lds, st>>>(a);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_slabs, int B, int H,
+                                 int W, int cin, int cout, int flags, const float* in_scale,
+                                 const float* in_shift, tdx_stream_t stream) {
+  if (!in || !dy || !dw_slabs || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  if (cin % 64 || cout % 64) return TDX_E_SHAPE;
+  const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+  if (in_bn && (!in_scale || !in_shift)) return TDX_E_BADARG;
+  int64_t M64 = (int64_t)B * H * W;
+  if (M64 >= (1ll << 31) - 64) return TDX_E_SHAPE;
+  WgradCfg c = pick_wgrad(M64, cin, cout);
+  WgradArgs a;
+  a.in = in; a.dy = dy; a.slabs = dw_slabs; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
+  a.tilesCi = cin / c.bn; a.chunk = c.chunk;
+  hipStream_t st = to_stream(stream);
+  if (c.bm == 128 && c.bn == 128) return launch_wgrad<128, 128>(a, c.splits, in_bn, st);
+  if (c.bm == 128 && c.bn == 64) return launch_wgrad<128, 64>(a, c.splits, in_bn, st);
+  if (c.bm == 64 && c.bn == 128) return launch_wgrad<64, 128>(a, c.splits, in_bn, st);
+  return launch_wgrad<64, 64>(a, c.splits, in_bn, st);
+}
+
+// sum the split-K slabs in a fixed order and write the OIHW gradient
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                    int splits, int cout, int cin) {
+  const int64_t n = (int64_t)cout * 9 * cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+    const int ci = (int)(i % cin);
+    const int tap = (int)((i / cin) % 9);
+    const int co = (int)(i / ((int64_t)9 * cin));
+    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+  }
+}
+
+extern "C" int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, int cout,
+                                        int cin, tdx_stream_t stream) {
+  if (!dw_slabs || !dw_oihw || splits <= 0 || cout <= 0 || cin <= 0) return TDX_E_BADARG;
+  int64_t n = (int64_t)cout * 9 * cin;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  wgrad_reduce_kernel<<<grid, 256, 0, to_stream(stream)>>>(dw_slabs, dw_oihw, splits, cout, cin);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ----------------------------------------------------------------- packing
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                    float* __restrict__ wd, int cout, int cin) {
+  const int64_t n = (int64_t)cout * cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes the forward pack [co][tap][ci] (coalesced writes)
+    const int ci = (int)(i % cin);
+    const int tap = (int)((i / cin) % 9);
+    const int co = (int)(i / ((int64_t)9 * cin));
+    const float v = w[((size_t)co * cin + ci) * 9 + tap];
+    if (wf) wf[i] = v;
+    // dgrad pack [ci][8-tap][co]: dIn[p][ci] = sum dy[p + tap'][co] * W[co][ci][flip(tap')]
+    if (wd) wd[((size_t)ci * 9 + (8 - tap)) * cout + co] = v;
+  }
+}
+
+extern "C" int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout,
+                                int cin, tdx_stream_t stream) {
+  if (!w_oihw || cout <= 0 || cin <= 0) return TDX_E_BADARG;
+  int64_t n = (int64_t)cout * cin * 9;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  pack_conv3x3_kernel<<<grid, 256, 0, to_stream(stream)>>>(w_oihw, w_fwd, w_dgrad, cout, cin);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,267 @@
+// HBM-bound elementwise kernels of the DDPM path: q_sample (diffusion.py:177-190),
+// the reverse-process update (diffusion.py:272-274), MSE loss (diffusion.py:231),
+// Adam (diffusion.py:211/236), plus the roofline probes used by bench.py.
+#include "common.h"
+
+// ------------------------------------------------------------------ q_sample
+// x_t = sqrt_ac[t[n]] * x0 + sqrt_1mac[t[n]] * noise ; 16 B per lane per tensor.
+__global__ void q_sample_kernel(const float4* __restrict__ x0, const float4* __restrict__ noise,
+                                const int64_t* __restrict__ t, const float* __restrict__ sqrt_ac,
+                                const float* __restrict__ sqrt_1mac, float4* __restrict__ x_t,
+                                int64_t n4, int per_sample4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int s = (int)(i / per_sample4);
+    int64_t ts = t[s];
+    float a = sqrt_ac[ts], b = sqrt_1mac[ts];
+    float4 x = x0[i], e = noise[i], o;
+    // two roundings per term like the reference's a*x0 + b*noise (no fma contraction)
+    o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(b, e.x));
+    o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(b, e.y));
+    o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(b, e.z));
+    o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(b, e.w));
+    x_t[i] = o;
+  }
+}
+
+__global__ void q_sample_philox_kernel(const float4* __restrict__ x0, const int64_t* __restrict__ t,
+                                       const float* __restrict__ sqrt_ac,
+                                       const float* __restrict__ sqrt_1mac,
+                                       float4* __restrict__ x_t, float4* __restrict__ noise_out,
+                                       int64_t n4, int per_sample4, uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int s = (int)(i / per_sample4);
+    int64_t ts = t[s];
+    float a = sqrt_ac[ts], b = sqrt_1mac[ts];
+    float4 e = philox_normal4((uint64_t)i, offset, seed);
+    float4 x = x0[i], o;
+    o.x = __fadd_rn(__fmul_rn(a, x.x), __fmul_rn(b, e.x));
+    o.y = __fadd_rn(__fmul_rn(a, x.y), __fmul_rn(b, e.y));
+    o.z = __fadd_rn(__fmul_rn(a, x.z), __fmul_rn(b, e.z));
+    o.w = __fadd_rn(__fmul_rn(a, x.w), __fmul_rn(b, e.w));
+    x_t[i] = o;
+    noise_out[i] = e;
+  }
+}
+
+static int ew_grid(int64_t n_items, int block) {
+  int64_t g = (n_items + block - 1) / block;
+  if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int tdx_q_sample(const float* x0, const float* noise, const int64_t* t,
+                            const float* sqrt_ac, const float* sqrt_1mac, float* x_t, int batch,
+                            int per_sample, tdx_stream_t stream) {
+  if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t || batch <= 0 || per_sample <= 0)
+    return TDX_E_BADARG;
+  if (per_sample % 4) return TDX_E_SHAPE;
+  int64_t n4 = (int64_t)batch * per_sample / 4;
+  q_sample_kernel<<<ew_grid(n4, 256), 256, 0, to_stream(stream)>>>(
+      (const float4*)x0, (const float4*)noise, t, sqrt_ac, sqrt_1mac, (float4*)x_t, n4,
+      per_sample / 4);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_q_sample_philox(const float* x0, const int64_t* t, const float* sqrt_ac,
+                                   const float* sqrt_1mac, float* x_t, float* noise_out, int batch,
+                                   int per_sample, uint64_t seed, uint64_t offset,
+                                   tdx_stream_t stream) {
+  if (!x0 || !t || !sqrt_ac || !sqrt_1mac || !x_t || !noise_out || batch <= 0 || per_sample <= 0)
+    return TDX_E_BADARG;
+  if (per_sample % 4) return TDX_E_SHAPE;
+  int64_t n4 = (int64_t)batch * per_sample / 4;
+  q_sample_philox_kernel<<<ew_grid(n4, 256), 256, 0, to_stream(stream)>>>(
+      (const float4*)x0, t, sqrt_ac, sqrt_1mac, (float4*)x_t, (float4*)noise_out, n4,
+      per_sample / 4, seed, offset);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------- p_sample step
+// x' = c1*(x - c2*eps) + sigma*z, evaluated in the reference's operation order
+// (diffusion.py:272-274): mul, sub, mul, mul, add - each rounded separately.
+__device__ static inline float p_step(float x, float e, float z, float c1, float c2, float sg) {
+  float inner = __fsub_rn(x, __fmul_rn(c2, e));
+  return __fadd_rn(__fmul_rn(c1, inner), __fmul_rn(sg, z));
+}
+
+template <bool PHILOX>
+__global__ void p_sample_kernel(float4* __restrict__ xo, const float4* __restrict__ x,
+                                const float4* __restrict__ eps, const float4* __restrict__ z,
+                                const float* __restrict__ coef, const int32_t* __restrict__ t_idx,
+                                int64_t n4, uint64_t seed) {
+  const int t = *t_idx;
+  const float c1 = coef[3 * t + 0], c2 = coef[3 * t + 1], sg = coef[3 * t + 2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 xv = x[i], ev = eps[i], zv = make_float4(0.f, 0.f, 0.f, 0.f), o;
+    if (PHILOX) {
+      if (t > 0) zv = philox_normal4((uint64_t)i, (uint64_t)t, seed);
+    } else if (z) {
+      zv = z[i];
+    }
+    o.x = p_step(xv.x, ev.x, zv.x, c1, c2, sg);
+    o.y = p_step(xv.y, ev.y, zv.y, c1, c2, sg);
+    o.z = p_step(xv.z, ev.z, zv.z, c1, c2, sg);
+    o.w = p_step(xv.w, ev.w, zv.w, c1, c2, sg);
+    xo[i] = o;
+  }
+}
+
+extern "C" int tdx_p_sample_step(float* x_out, const float* x, const float* eps, const float* z,
+                                 const float* coef, const int32_t* t_idx, int64_t n,
+                                 tdx_stream_t stream) {
+  if (!x_out || !x || !eps || !coef || !t_idx || n <= 0) return TDX_E_BADARG;
+  if (n % 4) return TDX_E_SHAPE;
+  p_sample_kernel<false><<<ew_grid(n / 4, 256), 256, 0, to_stream(stream)>>>(
+      (float4*)x_out, (const float4*)x, (const float4*)eps, (const float4*)z, coef, t_idx, n / 4,
+      0);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_p_sample_step_philox(float* x_out, const float* x, const float* eps,
+                                        const float* coef, const int32_t* t_idx, int64_t n,
+                                        uint64_t seed, tdx_stream_t stream) {
+  if (!x_out || !x || !eps || !coef || !t_idx || n <= 0) return TDX_E_BADARG;
+  if (n % 4) return TDX_E_SHAPE;
+  p_sample_kernel<true><<<ew_grid(n / 4, 256), 256, 0, to_stream(stream)>>>(
+      (float4*)x_out, (const float4*)x, (const float4*)eps, nullptr, coef, t_idx, n / 4, seed);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ MSE loss
+__global__ void mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                float* __restrict__ d_a, float k, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    d_a[i] = (a[i] - b[i]) * k;
+}
+
+// single block, fixed summation order -> deterministic
+__global__ void __launch_bounds__(1024) mse_loss_kernel(const float* __restrict__ a,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ out, int64_t n) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    float d = a[i] - b[i];
+    acc += (double)d * d;
+  }
+  // wave reduce in double via two float halves is overkill: shuffle the double as 2x32 bits
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    long long v = __double_as_longlong(acc);
+    int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64);
+    int hi = __shfl_xor((int)(v >> 32), o, 64);
+    acc += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[0] = (float)(s / (double)n);
+  }
+}
+
+extern "C" int tdx_mse_loss(const float* a, const float* b, float* loss_out, float* d_a,
+                            float gscale, int64_t n, tdx_stream_t stream) {
+  if (!a || !b || n <= 0) return TDX_E_BADARG;
+  if (loss_out) {
+    mse_loss_kernel<<<1, 1024, 0, to_stream(stream)>>>(a, b, loss_out, n);
+    TDX_CHECK_LAUNCH();
+  }
+  if (d_a) {
+    mse_grad_kernel<<<ew_grid(n, 256), 256, 0, to_stream(stream)>>>(a, b, d_a,
+                                                                     2.0f * gscale / (float)n, n);
+    TDX_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------- Adam
+// torch.optim.Adam defaults, single-tensor formulation:
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+//   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_bc1,
+                            float b1, float b2, float eps, float inv_sqrt_bc2, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gs;
+    float mi = m[i] * b1 + (1.0f - b1) * gi;
+    float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - lr_bc1 * (mi / denom);
+  }
+}
+
+extern "C" int tdx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                             float grad_scale, tdx_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return TDX_E_BADARG;
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  adam_kernel<<<ew_grid(n, 256), 256, 0, to_stream(stream)>>>(
+      param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps,
+      (float)(1.0 / sqrt(bc2)), grad_scale);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// -------------------------------------------------------------------- probes
+// fp32 MFMA peak: 4 independent 32x32x2 accumulator chains per wave, 4 waves per block.
+__global__ void __launch_bounds__(256) probe_mfma_kernel(float* out, int iters) {
+  f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+  float a = (float)(threadIdx.x & 7) * 0.001f, b = (float)(threadIdx.x & 3) * 0.002f;
+  for (int i = 0; i < iters; ++i) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc3, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream) {
+  if (!out || iters <= 0 || blocks <= 0) return TDX_E_BADARG;
+  probe_mfma_kernel<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                  int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+extern "C" int tdx_probe_stream_copy(const float* src, float* dst, int64_t n, tdx_stream_t stream) {
+  if (!src || !dst || n <= 0 || (n % 4)) return TDX_E_BADARG;
+  probe_copy_kernel<<<2048, 256, 0, to_stream(stream)>>>((const float4*)src, (float4*)dst, n / 4);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_version(void) { return TDX_VERSION; }
+
+extern "C" const char* tdx_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case TDX_E_BADARG: return "tdx: bad argument";
+    case TDX_E_SHAPE: return "tdx: unsupported shape";
+    case TDX_E_WORKSPACE: return "tdx: workspace too small";
+    case TDX_E_STATE: return "tdx: invalid state";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "tdx: unknown error";
+  }
+}

@@ -1,0 +1,569 @@
+// HBM-bound spatial glue of the UNet, channels-last, with BatchNorm+ReLU applied
+// on load so that normalised activations are never materialised:
+//   MaxPool2d(2, ceil_mode=True)                 diffusion.py:101, 120-124
+//   bilinear resize, align_corners=True          diffusion.py:102, 135-159
+//   initial_conv (Cin = 1) / final_conv (Cout = 1)   diffusion.py:28, 98, 116, 160
+// and their backward passes.
+#include "internal.h"
+
+__device__ static inline float4 bnrelu4(float4 v, const float4& sc, const float4& sh) {
+  v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+  v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+  v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+  v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+  return v;
+}
+
+static inline int ew_grid(int64_t n, int block = 256, int cap = 4096) {
+  int64_t g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------- max-pool
+template <bool BN>
+__global__ void maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ out, int B,
+                                   int H, int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
+  const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float4 sc, sh;
+    if (BN) {
+      sc = *reinterpret_cast<const float4*>(scale + c);
+      sh = *reinterpret_cast<const float4*>(shift + c);
+    }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int ih = 2 * oh + dh, iw = 2 * ow + dw;
+        if (ih < H && iw < W) {
+          float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)b * H + ih) * W + iw) * C + c);
+          if (BN) v = bnrelu4(v, sc, sh);
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
+          m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    *reinterpret_cast<float4*>(out + i * 4) = m;
+  }
+}
+
+extern "C" int tdx_maxpool2_ceil_fwd(const float* y, const float* scale, const float* shift,
+                                     float* out, int B, int H, int W, int C, tdx_stream_t stream) {
+  if (!y || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return TDX_E_BADARG;
+  if (C % 4) return TDX_E_SHAPE;
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  if (scale) maxpool_fwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, out, B, H, W, C);
+  else maxpool_fwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, out, B, H, W, C);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// One thread owns one 2x2 window (windows do not overlap): route the pooled
+// gradient to the FIRST maximum in scan order (ATen: `val > maxval`), add the
+// skip-path gradient, and write all (up to) four input positions.
+template <bool BN>
+__global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const float* __restrict__ g_out,
+                                   const float* __restrict__ skip, float* __restrict__ g_in, int B,
+                                   int H, int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
+  const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float4 sc, sh;
+    if (BN) {
+      sc = *reinterpret_cast<const float4*>(scale + c);
+      sh = *reinterpret_cast<const float4*>(shift + c);
+    }
+    const float4 go = *reinterpret_cast<const float4*>(g_out + i * 4);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
+      if (ih < H && iw < W) {
+        float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)b * H + ih) * W + iw) * C + c);
+        if (BN) v = bnrelu4(v, sc, sh);
+        if (v.x > m[0]) { m[0] = v.x; arg[0] = k; }
+        if (v.y > m[1]) { m[1] = v.y; arg[1] = k; }
+        if (v.z > m[2]) { m[2] = v.z; arg[2] = k; }
+        if (v.w > m[3]) { m[3] = v.w; arg[3] = k; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
+      if (ih < H && iw < W) {
+        const int64_t off = (((int64_t)b * H + ih) * W + iw) * C + c;
+        float4 r = skip ? *reinterpret_cast<const float4*>(skip + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arg[0] == k) r.x += go.x;
+        if (arg[1] == k) r.y += go.y;
+        if (arg[2] == k) r.z += go.z;
+        if (arg[3] == k) r.w += go.w;
+        *reinterpret_cast<float4*>(g_in + off) = r;
+      }
+    }
+  }
+}
+
+extern "C" int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const float* shift,
+                                     const float* g_out, const float* skip_grad, float* g_in, int B,
+                                     int H, int W, int C, tdx_stream_t stream) {
+  if (!y || !g_out || !g_in || B <= 0 || H <= 0 || W <= 0 || C <= 0) return TDX_E_BADARG;
+  if (C % 4) return TDX_E_SHAPE;
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  if (scale) maxpool_bwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
+  else maxpool_bwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------- bilinear
+// align_corners=True source coordinate, fp32 exactly like ATen:
+//   scale = (in-1)/(out-1);  src = scale*dst;  i0 = (int)src;  i1 = i0 + (i0 < in-1);  l1 = src - i0
+struct AxisTap {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ static inline AxisTap axis_tap(int dst, float scale, int n_in) {
+  AxisTap t;
+  const float src = scale * (float)dst;
+  t.i0 = min((int)src, n_in - 1);
+  t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+
+template <bool BN>
+__global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                    const float* __restrict__ shift,
+                                    const float* __restrict__ addend, float* __restrict__ out, int B,
+                                    int Hi, int Wi, int Ho, int Wo, int C, int ocs, int ocoff,
+                                    float sch, float scw) {
+  const int c4n = C / 4;
+  const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const AxisTap th = axis_tap(oh, sch, Hi), tw = axis_tap(ow, scw, Wi);
+    float4 sc, sh, ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BN) {
+      sc = *reinterpret_cast<const float4*>(scale + c);
+      sh = *reinterpret_cast<const float4*>(shift + c);
+    }
+    if (addend) ad = *reinterpret_cast<const float4*>(addend + (int64_t)b * C + c);
+    const float* base = in + (int64_t)b * Hi * Wi * C + c;
+    auto ld = [&](int h, int w) {
+      float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)h * Wi + w) * C);
+      if (BN) v = bnrelu4(v, sc, sh);
+      v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+      return v;
+    };
+    const float4 v00 = ld(th.i0, tw.i0), v01 = ld(th.i0, tw.i1);
+    const float4 v10 = ld(th.i1, tw.i0), v11 = ld(th.i1, tw.i1);
+    float4 o;
+    // width first, then height (ATen's separable evaluation order)
+#define LERP(k)                                            \
+    {                                                      \
+      const float top = tw.l0 * v00.k + tw.l1 * v01.k;     \
+      const float bot = tw.l0 * v10.k + tw.l1 * v11.k;     \
+      o.k = th.l0 * top + th.l1 * bot;                     \
+    }
+    LERP(x) LERP(y) LERP(z) LERP(w)
+#undef LERP
+    *reinterpret_cast<float4*>(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + ocoff + c) = o;
+  }
+}
+
+static inline float ac_scale(int n_in, int n_out) {
+  return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+}
+
+extern "C" int tdx_bilinear_ac_fwd(const float* in, const float* scale, const float* shift,
+                                   const float* addend, float* out, int B, int Hi, int Wi, int Ho,
+                                   int Wo, int C, int out_cstride, int out_coff,
+                                   tdx_stream_t stream) {
+  if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return TDX_E_BADARG;
+  if (C % 4 || out_cstride % 4 || out_coff % 4 || out_coff + C > out_cstride) return TDX_E_SHAPE;
+  const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
+  const float sch = ac_scale(Hi, Ho), scw = ac_scale(Wi, Wo);
+  if (scale)
+    bilinear_fwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+        in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
+  else
+    bilinear_fwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+        in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// Adjoint (gather form): every input position sums the output positions whose
+// two taps touch it.  Candidate outputs of input index i lie in
+// [ (i-1)/scale , (i+1)/scale ]; each candidate's taps are recomputed with the
+// forward's exact arithmetic, so forward and backward use identical weights.
+#define BIL_MAXC 8
+__device__ static inline void axis_adjoint(int i, float scale, int n_in, int n_out, int& lo,
+                                           float (&w)[BIL_MAXC]) {
+  int hi;
+  if (scale > 0.f) {
+    lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
+    hi = min(n_out - 1, (int)ceilf((float)(i + 1) / scale) + 1);
+  } else {
+    lo = 0;
+    hi = n_out - 1;
+  }
+  if (hi - lo + 1 > BIL_MAXC) hi = lo + BIL_MAXC - 1;  // host guarantees this never truncates
+#pragma unroll
+  for (int k = 0; k < BIL_MAXC; ++k) {
+    const int o = lo + k;
+    float wk = 0.f;
+    if (o <= hi) {
+      const AxisTap t = axis_tap(o, scale, n_in);
+      if (t.i0 == i) wk += t.l0;
+      if (t.i1 == i) wk += t.l1;
+    }
+    w[k] = wk;
+  }
+}
+
+__global__ void bilinear_bwd_kernel(const float* __restrict__ g_out, float* __restrict__ g_in, int B,
+                                    int Hi, int Wi, int Ho, int Wo, int C, int gcs, int gcoff,
+                                    float sch, float scw) {
+  const int c4n = C / 4;
+  const int64_t n = (int64_t)B * Hi * Wi * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int iw = (int)(p % Wi); p /= Wi;
+    const int ih = (int)(p % Hi);
+    const int b = (int)(p / Hi);
+    int hlo, wlo;
+    float wh[BIL_MAXC], ww[BIL_MAXC];
+    axis_adjoint(ih, sch, Hi, Ho, hlo, wh);
+    axis_adjoint(iw, scw, Wi, Wo, wlo, ww);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < BIL_MAXC; ++a) {
+      if (wh[a] == 0.f) continue;
+#pragma unroll
+      for (int d = 0; d < BIL_MAXC; ++d) {
+        if (ww[d] == 0.f) continue;
+        const float4 g = *reinterpret_cast<const float4*>(
+            g_out + (((int64_t)b * Ho + hlo + a) * Wo + wlo + d) * gcs + gcoff + c);
+        const float w = wh[a] * ww[d];
+        acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y);
+        acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(g_in + i * 4) = acc;
+  }
+}
+
+// host-side check that BIL_MAXC candidates cover every contributor of every input index
+static bool adjoint_window_ok(int n_in, int n_out) {
+  const float scale = ac_scale(n_in, n_out);
+  if (!(scale > 0.f)) return n_out <= BIL_MAXC;
+  for (int i = 0; i < n_in; ++i) {
+    int lo = (int)floorf((float)(i - 1) / scale) - 1;
+    if (lo < 0) lo = 0;
+    int hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (hi > n_out - 1) hi = n_out - 1;
+    if (hi - lo + 1 > BIL_MAXC) return false;
+  }
+  return true;
+}
+
+extern "C" int tdx_bilinear_ac_bwd(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho,
+                                   int Wo, int C, int g_cstride, int g_coff, tdx_stream_t stream) {
+  if (!g_out || !g_in || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return TDX_E_BADARG;
+  if (C % 4 || g_cstride % 4 || g_coff % 4 || g_coff + C > g_cstride) return TDX_E_SHAPE;
+  if (!adjoint_window_ok(Hi, Ho) || !adjoint_window_ok(Wi, Wo)) return TDX_E_SHAPE;
+  const int64_t n = (int64_t)B * Hi * Wi * (C / 4);
+  bilinear_bwd_kernel<<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+      g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------- per-(n,c) sum over pixels
+// out[n][c] = sum_{h,w} g[n][h][w][c]   (gradient of the broadcast time/class add)
+__global__ void __launch_bounds__(256)
+pixel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int HW, int C) {
+  extern __shared__ float red[];  // [rgroups][C]
+  const int c4n = C / 4, col = threadIdx.x % c4n, rg = threadIdx.x / c4n, rgroups = 256 / c4n;
+  const float* base = g + (int64_t)blockIdx.x * HW * C + col * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = rg; p < HW; p += rgroups) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)p * C);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(red + rg * C + col * 4) = s;
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < rgroups; ++k) v += red[k * C + i];
+    out[(int64_t)blockIdx.x * C + i] = v;
+  }
+}
+
+int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t st) {
+  if (C % 4 || C > 1024 || 256 % (C / 4)) return TDX_E_SHAPE;
+  const int rgroups = 256 / (C / 4);
+  pixel_sum_kernel<<<B, 256, (size_t)rgroups * C * sizeof(float), st>>>(g, out, HW, C);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[i] = sum_b partial[b*stride + i], i < count, fixed order, double accumulation
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                       int nblk, int stride, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * stride + i];
+  out[i] = (float)s;
+}
+
+int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
+                        hipStream_t st) {
+  reduce_partials_kernel<<<cdiv(count, 128), 128, 0, st>>>(partial, out, nblk, stride, count);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// --------------------------------------------------- initial_conv (1 -> 64)
+// out[p][co] = b[co] + sum_tap x[p+tap] * W[co][tap]; memory-bound (256 B written per pixel).
+#define IC_CO 64
+__global__ void __launch_bounds__(256)
+initial_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+  __shared__ float ws[9][IC_CO];
+  __shared__ float bs[IC_CO];
+  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];  // w is [co][tap]
+  if (threadIdx.x < IC_CO) bs[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int co = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
+  const int64_t M = (int64_t)B * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
+    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+    float4 acc = make_float4(bs[co], bs[co + 1], bs[co + 2], bs[co + 3]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        const float xv = x[p + (tap / 3 - 1) * W + (tap % 3 - 1)];
+        acc.x = fmaf(xv, ws[tap][co], acc.x);
+        acc.y = fmaf(xv, ws[tap][co + 1], acc.y);
+        acc.z = fmaf(xv, ws[tap][co + 2], acc.z);
+        acc.w = fmaf(xv, ws[tap][co + 3], acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(out + p * IC_CO + co) = acc;
+  }
+}
+
+int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
+                         int W, hipStream_t st) {
+  const int64_t M = (int64_t)B * H * W;
+  initial_conv_fwd_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(x, w, bias, out, B, H, W);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// dW[co][tap] = sum_p g[p][co] * x[p+tap];  db[co] = sum_p g[p][co]
+// partial[blk][640]: [co*9+tap] then [576+co]
+#define ICW_PIX 256
+__global__ void __launch_bounds__(256)
+initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                          float* __restrict__ partial, int B, int H, int W) {
+  __shared__ float red[4][10][IC_CO];
+  const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int64_t M = (int64_t)B * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int64_t p = p0 + pg; p < p1; p += 4) {
+    const float gv = g[p * IC_CO + co];
+    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        acc[tap] = fmaf(gv, x[p + (tap / 3 - 1) * W + (tap % 3 - 1)], acc[tap]);
+    }
+    acc[9] += gv;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) red[pg][k][co] = acc[k];
+  __syncthreads();
+  if (pg == 0) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float v = red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co];
+      partial[(size_t)blockIdx.x * 640 + (k < 9 ? co * 9 + k : 576 + co)] = v;
+    }
+  }
+}
+
+int tdx_initial_conv_wgrad_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, ICW_PIX); }
+
+int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
+                           int B, int H, int W, hipStream_t st) {
+  const int nblk = tdx_initial_conv_wgrad_blocks(B, H, W);
+  initial_conv_wgrad_kernel<<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
+  TDX_CHECK_LAUNCH();
+  // columns [0,576) -> dw (contiguous [co][tap]), columns [576,640) -> db
+  int rc = tdx_reduce_partials(partial, dw, nblk, 640, 576, st);
+  if (rc) return rc;
+  return tdx_reduce_partials(partial + 576, db, nblk, 640, 64, st);
+}
+
+// ----------------------------------------------------- final_conv (64 -> 1)
+// out[p] = b + sum_tap sum_ci in[p+tap][ci] * W[ci][tap]; 16 lanes per pixel, float4 of
+// channels per lane, shuffle-reduced.
+__global__ void __launch_bounds__(256)
+final_conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                      const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+  __shared__ float ws[9][IC_CO];
+  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];  // w is [ci][tap]
+  __syncthreads();
+  const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
+  const int64_t M = (int64_t)B * H * W;
+  const int64_t Mpad = (M + 15) / 16 * 16;
+  const float bv = bias[0];
+  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
+    float s = 0.f;
+    if (p < M) {
+      const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(
+              in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
+          s = fmaf(v.x, ws[tap][ci], s);
+          s = fmaf(v.y, ws[tap][ci + 1], s);
+          s = fmaf(v.z, ws[tap][ci + 2], s);
+          s = fmaf(v.w, ws[tap][ci + 3], s);
+        }
+      }
+    }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if ((threadIdx.x & 15) == 0 && p < M) out[p] = s + bv;
+  }
+}
+
+int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
+                       int W, hipStream_t st) {
+  const int64_t M = (int64_t)B * H * W;
+  final_conv_fwd_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(in, w, bias, out, B, H, W);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// g_in[p][ci] = sum_tap g_out[p - tapoffset] * W[ci][tap]
+__global__ void __launch_bounds__(256)
+final_conv_dgrad_kernel(const float* __restrict__ g_out, const float* __restrict__ w,
+                        float* __restrict__ g_in, int B, int H, int W) {
+  __shared__ float ws[9][IC_CO];
+  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];
+  __syncthreads();
+  const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
+  const int64_t M = (int64_t)B * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
+    const int r = (int)(p % (H * W)), ih = r / W, iw = r % W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // output pixel (oh, ow) saw this input through tap (kh, kw) iff oh = ih - kh + 1
+      const int oh = ih - (tap / 3 - 1), ow = iw - (tap % 3 - 1);
+      if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+        const float gv = g_out[p - (tap / 3 - 1) * W - (tap % 3 - 1)];
+        acc.x = fmaf(gv, ws[tap][ci], acc.x);
+        acc.y = fmaf(gv, ws[tap][ci + 1], acc.y);
+        acc.z = fmaf(gv, ws[tap][ci + 2], acc.z);
+        acc.w = fmaf(gv, ws[tap][ci + 3], acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(g_in + p * IC_CO + ci) = acc;
+  }
+}
+
+int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
+                         hipStream_t st) {
+  const int64_t M = (int64_t)B * H * W;
+  final_conv_dgrad_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(g_out, w, g_in, B, H, W);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// dW[ci][tap] = sum_p g_out[p] * in[p+tap][ci];  db = sum_p g_out[p]
+// partial[blk][640]: [ci*9+tap], [576] = db partial (rest of the row unused)
+__global__ void __launch_bounds__(256)
+final_conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ g_out,
+                        float* __restrict__ partial, int B, int H, int W) {
+  __shared__ float red[4][10][IC_CO];
+  const int ci = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int64_t M = (int64_t)B * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int64_t p = p0 + pg; p < p1; p += 4) {
+    const float gv = g_out[p];
+    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        acc[tap] = fmaf(gv, in[(p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci], acc[tap]);
+    }
+    acc[9] += gv;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) red[pg][k][ci] = acc[k];
+  __syncthreads();
+  if (pg == 0) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float v = red[0][k][ci] + red[1][k][ci] + red[2][k][ci] + red[3][k][ci];
+      if (k < 9) partial[(size_t)blockIdx.x * 640 + ci * 9 + k] = v;
+      else if (ci == 0) partial[(size_t)blockIdx.x * 640 + 576] = v;
+    }
+  }
+}
+
+int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
+                         int B, int H, int W, hipStream_t st) {
+  const int nblk = tdx_initial_conv_wgrad_blocks(B, H, W);
+  final_conv_wgrad_kernel<<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
+  TDX_CHECK_LAUNCH();
+  int rc = tdx_reduce_partials(partial, dw, nblk, 640, 576, st);
+  if (rc) return rc;
+  return tdx_reduce_partials(partial + 576, db, nblk, 640, 1, st);
+}

@@ -1,0 +1,167 @@
+// Time / class conditioning path (tiny FLOPs, latency-bound):
+//   emb = Linear(256,256)(SiLU(Linear(1,256)(float(t)))) [+ Embedding(10,256)[y]]
+//         diffusion.py:21-25, 111-113; conditional_diffusion.py:31, 121-125
+//   t_k = time_proj_k(emb), 1x1 convs on a (B,256,1,1) map == linear 256 -> 128|256|512
+//         diffusion.py:105-107, 130-132
+// and the backward of all of it.  Kept in fp32 throughout: t is the raw integer
+// step (0..999), so pre-activations reach the hundreds.
+#include "internal.h"
+
+#define TD 256  // time_dim
+
+__device__ static inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ static inline float silu_grad_f(float x) {
+  const float s = 1.0f / (1.0f + expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// One block per sample.  Each wave computes dot products cooperatively (4 floats per lane
+// of a 256-long row, then a wave reduction) so weight rows are read as full 1 KiB lines.
+__global__ void __launch_bounds__(256)
+time_embed_fwd_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ y,
+                      const float* __restrict__ w1, const float* __restrict__ b1,
+                      const float* __restrict__ w2, const float* __restrict__ b2,
+                      const float* __restrict__ cls, const float* __restrict__ pw1,
+                      const float* __restrict__ pb1, const float* __restrict__ pw2,
+                      const float* __restrict__ pb2, const float* __restrict__ pw3,
+                      const float* __restrict__ pb3, float* __restrict__ pre_out,
+                      float* __restrict__ emb_out, float* __restrict__ t1, float* __restrict__ t2,
+                      float* __restrict__ t3) {
+  __shared__ __attribute__((aligned(16))) float h[TD];
+  __shared__ __attribute__((aligned(16))) float emb[TD];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float tf = (float)t[n];
+  const float pre = fmaf(w1[tid], tf, b1[tid]);  // Linear(1, 256): weight (256,1)
+  if (pre_out) pre_out[(size_t)n * TD + tid] = pre;
+  h[tid] = silu_f(pre);
+  __syncthreads();
+  const float4 hv = *reinterpret_cast<const float4*>(h + lane * 4);
+  for (int i = wave; i < TD; i += 4) {
+    const float4 wv = *reinterpret_cast<const float4*>(w2 + (size_t)i * TD + lane * 4);
+    float s = wv.x * hv.x + wv.y * hv.y + wv.z * hv.z + wv.w * hv.w;
+    s = wave_sum(s);
+    if (lane == 0) {
+      float e = s + b2[i];
+      if (y) e += cls[(size_t)y[n] * TD + i];
+      emb[i] = e;
+    }
+  }
+  __syncthreads();
+  if (emb_out) emb_out[(size_t)n * TD + tid] = emb[tid];
+  const float4 ev = *reinterpret_cast<const float4*>(emb + lane * 4);
+  for (int o = wave; o < 128 + 256 + 512; o += 4) {
+    const float* wrow; float bias; float* dst;
+    if (o < 128) { wrow = pw1 + (size_t)o * TD; bias = pb1[o]; dst = t1 + (size_t)n * 128 + o; }
+    else if (o < 384) { wrow = pw2 + (size_t)(o - 128) * TD; bias = pb2[o - 128]; dst = t2 + (size_t)n * 256 + (o - 128); }
+    else { wrow = pw3 + (size_t)(o - 384) * TD; bias = pb3[o - 384]; dst = t3 + (size_t)n * 512 + (o - 384); }
+    const float4 wv = *reinterpret_cast<const float4*>(wrow + lane * 4);
+    float s = wv.x * ev.x + wv.y * ev.y + wv.z * ev.z + wv.w * ev.w;
+    s = wave_sum(s);
+    if (lane == 0) *dst = s + bias;
+  }
+}
+
+int tdx_time_embed_fwd(const int64_t* t, const int64_t* y, const float* const* P, float* pre,
+                       float* emb, float* t1, float* t2, float* t3, int B, hipStream_t st) {
+  time_embed_fwd_kernel<<<B, 256, 0, st>>>(
+      t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W], P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB],
+      P[TDX_P_TP1_W], P[TDX_P_TP1_B], P[TDX_P_TP2_W], P[TDX_P_TP2_B], P[TDX_P_TP3_W],
+      P[TDX_P_TP3_B], pre, emb, t1, t2, t3);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ backward
+// dW[o][j] = sum_n g[n][o] * x[n][j];  db[o] = sum_n g[n][o]     (thread per (o, j))
+__global__ void lin_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                 float* __restrict__ dw, float* __restrict__ db, int B, int O, int J) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * J) return;
+  const int o = idx / J, j = idx - o * J;
+  float s = 0.f, sb = 0.f;
+  for (int n = 0; n < B; ++n) {
+    const float gv = g[(size_t)n * O + o];
+    s = fmaf(gv, x[(size_t)n * J + j], s);
+    sb += gv;
+  }
+  dw[idx] = s;
+  if (j == 0 && db) db[o] = sb;
+}
+
+// gx[n][j] (+)= sum_o g[n][o] * W[o][j]     (thread per (n, j))
+__global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                 float* __restrict__ gx, int B, int O, int J, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * J) return;
+  const int n = idx / J, j = idx - n * J;
+  float s = accumulate ? gx[idx] : 0.f;
+  for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * O + o], w[(size_t)o * J + j], s);
+  gx[idx] = s;
+}
+
+// g_pre = g_h * silu'(pre);  dW1[j] = sum_n g_pre[n][j] * t[n];  db1[j] = sum_n g_pre[n][j]
+__global__ void time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
+                                   const int64_t* __restrict__ t, float* __restrict__ dw1,
+                                   float* __restrict__ db1, int B) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= TD) return;
+  float sw = 0.f, sb = 0.f;
+  for (int n = 0; n < B; ++n) {
+    const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
+    sw = fmaf(gp, (float)t[n], sw);
+    sb += gp;
+  }
+  dw1[j] = sw;
+  db1[j] = sb;
+}
+
+// h[n][j] = silu(pre[n][j])
+__global__ void silu_kernel(const float* __restrict__ pre, float* __restrict__ h, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i] = silu_f(pre[i]);
+}
+
+// dE[c][j] = sum_{n : y[n] == c} g_emb[n][j]   (nn.Embedding backward, fixed order)
+__global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int64_t* __restrict__ y,
+                                     float* __restrict__ de, int B, int ncls) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncls * TD) return;
+  const int c = idx / TD, j = idx - c * TD;
+  float s = 0.f;
+  for (int n = 0; n < B; ++n)
+    if ((int)y[n] == c) s += g_emb[(size_t)n * TD + j];
+  de[idx] = s;
+}
+
+// scratch: g_emb (B*256) | h (B*256) | g_h (B*256)
+int tdx_time_embed_bwd(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+                       const float* pre, const float* emb, const float* g_t1, const float* g_t2,
+                       const float* g_t3, float* scratch, int B, int ncls, hipStream_t st) {
+  float* g_emb = scratch;
+  float* h = scratch + (size_t)B * TD;
+  float* g_h = scratch + (size_t)2 * B * TD;
+  const float* gk[3] = {g_t1, g_t2, g_t3};
+  const int ok[3] = {128, 256, 512};
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k) {
+    lin_wgrad_kernel<<<cdiv(ok[k] * TD, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
+                                                            ok[k], TD);
+    TDX_CHECK_LAUNCH();
+    lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TD, k > 0);
+    TDX_CHECK_LAUNCH();
+  }
+  if (ncls > 0 && y) {
+    class_emb_bwd_kernel<<<cdiv(ncls * TD, 256), 256, 0, st>>>(g_emb, y, G[TDX_P_CLASS_EMB], B, ncls);
+    TDX_CHECK_LAUNCH();
+  }
+  silu_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(pre, h, B * TD);
+  TDX_CHECK_LAUNCH();
+  lin_wgrad_kernel<<<cdiv(TD * TD, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B,
+                                                       TD, TD);
+  TDX_CHECK_LAUNCH();
+  lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0);
+  TDX_CHECK_LAUNCH();
+  time_l1_bwd_kernel<<<1, 256, 0, st>>>(g_h, pre, t, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,163 @@
+"""Forward process (noise schedule + q_sample) and the reverse sampling loop,
+mirroring ForwardProcess / sample() of the reference (diffusion.py:165-190,
+254-276; conditional_diffusion.py:174-199, 354-386) on libtdx kernels."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+class ForwardProcess:
+    """diffusion.py:165-190.  ``betas`` / ``alphas`` / ``alphas_cumprod`` are CPU
+    fp32 tensors computed with the reference's expressions (bit-identical); device
+    copies of the derived tables are cached per device instead of being re-uploaded
+    on every call (the reference does two H2D copies per q_sample, diffusion.py:180,184)."""
+
+    def __init__(self, num_timesteps: int = 1000, beta_start: float = 1e-4, beta_end: float = 0.02):
+        self.num_timesteps = num_timesteps
+        self.betas = torch.linspace(beta_start, beta_end, num_timesteps)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self._dev = {}
+
+    def tables(self, device):
+        """(sqrt_ac, sqrt_1mac, coef[T,3]) on ``device``; coef rows are
+        (1/sqrt(alpha), (1-alpha)/sqrt(1-alpha_cumprod), sqrt(beta)), diffusion.py:272-274."""
+        device = torch.device(device)
+        key = (device.type, device.index)
+        tb = self._dev.get(key)
+        if tb is None:
+            sqrt_ac = torch.sqrt(self.alphas_cumprod)
+            sqrt_1mac = torch.sqrt(1.0 - self.alphas_cumprod)
+            coef = torch.stack([1 / torch.sqrt(self.alphas),
+                                (1 - self.alphas) / torch.sqrt(1 - self.alphas_cumprod),
+                                torch.sqrt(self.betas)], dim=1).contiguous()
+            tb = (sqrt_ac.to(device), sqrt_1mac.to(device), coef.to(device))
+            self._dev[key] = tb
+        return tb
+
+    def q_sample(self, device, x_0, t, noise: Optional[torch.Tensor] = None):
+        """x_t = sqrt(acp[t]) x_0 + sqrt(1-acp[t]) eps; returns (x_t, eps).
+
+        ``noise=None`` draws ``torch.randn_like(x_0)`` from x_0's default generator,
+        exactly the reference's RNG consumption (diffusion.py:178)."""
+        if noise is None:
+            noise = torch.randn_like(x_0).to(device)
+        x_0 = x_0.to(device)
+        if not x_0.is_cuda:
+            raise _lib.TdxError("q_sample runs on the GPU only (no CPU fallback)")
+        sqrt_ac, sqrt_1mac, _ = self.tables(x_0.device)
+        x_0 = x_0.contiguous().float()
+        noise = noise.contiguous().float()
+        t = t.to(x_0.device).contiguous().to(torch.int64)
+        B = x_0.shape[0]
+        if t.shape != (B,):
+            raise ValueError("t must have shape (B,)")
+        per = x_0.numel() // B
+        x_t = torch.empty_like(x_0)
+        st = torch.cuda.current_stream(x_0.device).cuda_stream
+        check(lib.tdx_q_sample(x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(),
+                               sqrt_1mac.data_ptr(), x_t.data_ptr(), B, per, st), "tdx_q_sample")
+        return x_t, noise
+
+    def q_sample_philox(self, x_0, t, seed: int, offset: int = 0):
+        """Throughput variant: noise generated in-kernel (Philox4x32-10 + Box-Muller)."""
+        if not x_0.is_cuda:
+            raise _lib.TdxError("q_sample runs on the GPU only (no CPU fallback)")
+        sqrt_ac, sqrt_1mac, _ = self.tables(x_0.device)
+        x_0 = x_0.contiguous().float()
+        t = t.contiguous().to(torch.int64)
+        B = x_0.shape[0]
+        x_t, noise = torch.empty_like(x_0), torch.empty_like(x_0)
+        st = torch.cuda.current_stream(x_0.device).cuda_stream
+        check(lib.tdx_q_sample_philox(x_0.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+                                      x_t.data_ptr(), noise.data_ptr(), B, x_0.numel() // B, seed, offset, st),
+              "tdx_q_sample_philox")
+        return x_t, noise
+
+
+def p_sample_step(diffusion: ForwardProcess, x, eps, t_idx, z=None, out=None):
+    """x_{t-1} = c1[t] (x - c2[t] eps) + sigma[t] z   (diffusion.py:272-274).
+    ``t_idx``: int32 device tensor holding t; ``z=None`` is the t == 0 branch."""
+    _, _, coef = diffusion.tables(x.device)
+    out = torch.empty_like(x) if out is None else out
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    check(lib.tdx_p_sample_step(out.data_ptr(), x.data_ptr(), eps.data_ptr(),
+                                None if z is None else z.data_ptr(), coef.data_ptr(), t_idx.data_ptr(),
+                                x.numel(), st), "tdx_p_sample_step")
+    return out
+
+
+@torch.no_grad()
+def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, y=None,
+                x_T: Optional[torch.Tensor] = None, noises=None, use_graph: bool = False,
+                philox_seed: Optional[int] = None):
+    """Reverse process, diffusion.py:254-276.
+
+    Default (``x_T is None and noises is None``): the reference's RNG consumption -
+    ``torch.randn(n,1,28,28)`` on the CPU generator moved to ``device``, then one
+    ``torch.randn_like(x)`` per step t = T-1..1 on the device generator.
+    ``noises``: mapping/sequence t -> z (recorded noise, parity tests).
+    ``philox_seed``: in-kernel noise, no z tensor at all (throughput mode).
+    ``use_graph``: capture one reverse step (UNet forward + update) into a HIP graph
+    and replay it T times; the step index lives in device memory.
+    """
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.TdxError("sampling runs on the GPU only (no CPU fallback)")
+    noise_model.eval()
+    x = (torch.randn(n_samples, 1, 28, 28) if x_T is None else x_T).to(device).float().contiguous()
+    if y is not None:
+        y = y.to(device)
+    T = diffusion.num_timesteps
+    _, _, coef = diffusion.tables(device)
+    t_idx = torch.empty(1, dtype=torch.int32, device=device)
+    t_vec = torch.empty(n_samples, dtype=torch.int64, device=device)
+    st = lambda: torch.cuda.current_stream(device).cuda_stream  # noqa: E731
+    x_next = torch.empty_like(x)
+    zbuf = torch.empty_like(x)
+
+    def step_kernels(use_z: bool):
+        eps = noise_model._run_forward(x, t_vec, y, mode=2)[0]
+        if philox_seed is not None:
+            check(lib.tdx_p_sample_step_philox(x_next.data_ptr(), x.data_ptr(), eps.data_ptr(), coef.data_ptr(),
+                                               t_idx.data_ptr(), x.numel(), philox_seed, st()), "tdx_p_sample_step")
+        else:
+            check(lib.tdx_p_sample_step(x_next.data_ptr(), x.data_ptr(), eps.data_ptr(),
+                                        zbuf.data_ptr() if use_z else None, coef.data_ptr(), t_idx.data_ptr(),
+                                        x.numel(), st()), "tdx_p_sample_step")
+        x.copy_(x_next)
+
+    graph = None
+    if use_graph:
+        t_idx.fill_(T - 1); t_vec.fill_(T - 1)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        x_keep = x.clone()
+        with torch.cuda.stream(side):
+            step_kernels(True)          # warm-up: first-launch attribute calls, packing
+        torch.cuda.current_stream(device).wait_stream(side)
+        x.copy_(x_keep)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_kernels(True)
+    for t in reversed(range(T)):
+        t_idx.fill_(t)
+        t_vec.fill_(t)
+        if philox_seed is None:
+            if t > 0:
+                if noises is not None:
+                    zbuf.copy_(noises[t].to(device))
+                else:
+                    zbuf.copy_(torch.randn_like(x))
+            else:
+                zbuf.zero_()
+        if graph is not None:
+            graph.replay()
+        else:
+            step_kernels(True)
+    return x

@@ -1,0 +1,293 @@
+"""Host side of the MI355X noise predictor: an ``nn.Module`` with the reference's
+constructor, ``state_dict`` and ``forward(x, t[, y])`` (diffusion.py:11-162,
+conditional_diffusion.py:14-172) whose compute is libtdx.so (include/tdx.h).
+
+The module tree below exists only to own parameters/buffers under the
+reference's names and to give the reference's default initialisation (same
+constructors in the same order => bit-identical weights under the same
+``torch.manual_seed``); none of the torch layers' ``forward`` is ever called.
+There is no CPU/eager fallback: a non-CUDA input raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import lib, check
+
+TIME_DIM = 256
+MODE_TRAIN, MODE_EVAL_GRAD, MODE_INFER = 0, 1, 2
+
+# (name, cin, cout) of the six two-conv stages in registration order
+_ENC = (("enc1", 64, 128), ("enc2", 128, 256), ("enc3", 256, 512))
+_DEC = (("dec3", 1024, 256), ("dec2", 512, 128), ("dec1", 256, 64))
+# conv/BN units in the order of TDX_P_UNIT0.. (include/tdx.h)
+_UNIT_PREFIX = (
+    ("enc1", 0), ("enc1", 3), ("enc2", 0), ("enc2", 3), ("enc3", 0), ("enc3", 3), ("bottleneck", 0),
+    ("dec3", 0), ("dec3", 3), ("dec2", 0), ("dec2", 3), ("dec1", 0), ("dec1", 3),
+)
+
+
+def _conv_bn_relu(cin, cout):
+    return [nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU()]
+
+
+def param_slot_names(cond: bool) -> List[Optional[str]]:
+    """state_dict key of every TDX_P_* slot (None where the slot is unused)."""
+    names: List[Optional[str]] = [
+        "time_embedding.0.weight", "time_embedding.0.bias",
+        "time_embedding.2.weight", "time_embedding.2.bias",
+        "class_embedding.weight" if cond else None,
+        "initial_conv.weight", "initial_conv.bias",
+    ]
+    for stage, idx in _UNIT_PREFIX:
+        names += [f"{stage}.{idx}.weight", f"{stage}.{idx}.bias",
+                  f"{stage}.{idx + 1}.weight", f"{stage}.{idx + 1}.bias"]
+    names += ["final_conv.weight", "final_conv.bias"]
+    for k in (1, 2, 3):
+        names += [f"time_proj{k}.weight", f"time_proj{k}.bias"]
+    return names
+
+
+def buffer_slot_names() -> List[str]:
+    out = []
+    for stage, idx in _UNIT_PREFIX:
+        out += [f"{stage}.{idx + 1}.running_mean", f"{stage}.{idx + 1}.running_var",
+                f"{stage}.{idx + 1}.num_batches_tracked"]
+    return out
+
+
+def backward_stage_params(cond: bool) -> List[List[str]]:
+    """Parameters whose gradient is final after each backward stage
+    (tdx_unet_backward stage order): used to bucket the gradient all-reduce."""
+    stages = [["final_conv.weight", "final_conv.bias"]]
+    for stage, idx in reversed(_UNIT_PREFIX):
+        stages.append([f"{stage}.{idx}.weight", f"{stage}.{idx}.bias",
+                       f"{stage}.{idx + 1}.weight", f"{stage}.{idx + 1}.bias"])
+    last = ["initial_conv.weight", "initial_conv.bias",
+            "time_embedding.0.weight", "time_embedding.0.bias",
+            "time_embedding.2.weight", "time_embedding.2.bias"]
+    if cond:
+        last.append("class_embedding.weight")
+    for k in (1, 2, 3):
+        last += [f"time_proj{k}.weight", f"time_proj{k}.bias"]
+    stages.append(last)
+    return stages
+
+
+class _Plan:
+    """One tdx_unet handle + workspace per (device, batch size)."""
+
+    def __init__(self, batch: int, num_classes: int, device: torch.device):
+        self.batch = batch
+        self.device = device
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(lib.tdx_unet_create(C.byref(h), batch, num_classes), "tdx_unet_create")
+        self.handle = h
+        self.ws_bytes = lib.tdx_unet_workspace_bytes(h, batch, MODE_TRAIN)
+        if self.ws_bytes == 0:
+            raise _lib.TdxError("tdx_unet_workspace_bytes returned 0")
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.generation = 0      # bumped by every forward that saves state
+        self.infer_key = None    # parameter versions the INFER pack was built from
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.tdx_unet_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _PtrTable:
+    """ctypes array of device pointers, rebuilt only when a tensor moves."""
+
+    def __init__(self):
+        self.key = None
+        self.arr = None
+
+    def get(self, tensors):
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        if key != self.key:
+            self.arr = (C.c_void_p * len(key))(*[k or None for k in key])
+            self.key = key
+        return self.arr
+
+
+class _UNetFunction(torch.autograd.Function):
+    """eps_hat = UNet(x, t[, y]); backward returns every parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, module, x, t, y, *params):
+        out, plan, mode = module._run_forward(x, t, y)
+        ctx.module = module
+        ctx.plan = plan
+        ctx.generation = plan.generation
+        ctx.saved_for = mode
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        module, plan = ctx.module, ctx.plan
+        if plan.generation != ctx.generation:
+            raise _lib.TdxError(
+                "backward() after another forward() on the same batch size: the saved "
+                "activations live in a per-batch-size workspace and were overwritten")
+        flat, views = module._grad_buffers(d_out.device)
+        module._run_backward(plan, d_out.contiguous(), views)
+        grads = tuple(views[name] for name in module._param_order)
+        return (None, None, None, None) + grads
+
+
+class NoiseModelBase(nn.Module):
+    """Shared implementation; ``NoiseModel`` in diffusion.py / conditional_diffusion.py
+    fixes ``num_classes``."""
+
+    def __init__(self, time_dim: int = TIME_DIM, num_classes: int = 0):
+        super().__init__()
+        if time_dim != TIME_DIM:
+            raise ValueError(f"libtdx is built for time_dim={TIME_DIM} (reference default)")
+        self.time_dim = time_dim
+        self.num_classes = int(num_classes)
+        # registration order == reference (diffusion.py:19-107): identical state_dict
+        # order and identical default init under the same seed
+        self.time_embedding = nn.Sequential(nn.Linear(1, time_dim), nn.SiLU(), nn.Linear(time_dim, time_dim))
+        if self.num_classes > 0:
+            self.class_embedding = nn.Embedding(self.num_classes, time_dim)
+        self.initial_conv = nn.Conv2d(1, 64, 3, padding=1)
+        for name, cin, cout in _ENC:
+            setattr(self, name, nn.Sequential(*_conv_bn_relu(cin, cout), *_conv_bn_relu(cout, cout)))
+        self.bottleneck = nn.Sequential(*_conv_bn_relu(512, 512))
+        for name, cin, cout in _DEC:
+            setattr(self, name, nn.Sequential(*_conv_bn_relu(cin, cout), *_conv_bn_relu(cout, cout)))
+        self.final_conv = nn.Conv2d(64, 1, 3, padding=1)
+        self.pool = nn.MaxPool2d(2, ceil_mode=True)
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        for k, c in ((1, 128), (2, 256), (3, 512)):
+            setattr(self, f"time_proj{k}", nn.Conv2d(time_dim, c, 1))
+
+        cond = self.num_classes > 0
+        self._slot_names = param_slot_names(cond)
+        self._buf_names = buffer_slot_names()
+        self._param_order = [n for n in self._slot_names if n is not None]
+        self._plans = {}
+        self._ptab_p, self._ptab_b, self._ptab_g = _PtrTable(), _PtrTable(), _PtrTable()
+        self._grad_flat = None
+        self._grad_views = None
+        self._buf_epoch = 0
+
+    # ---------------------------------------------------------------- plumbing
+    def _named(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _plan(self, batch: int, device: torch.device) -> _Plan:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), batch)
+        p = self._plans.get(key)
+        if p is None:
+            p = _Plan(batch, self.num_classes, device)
+            self._plans[key] = p
+        return p
+
+    def _param_ptrs(self):
+        d = self._named()
+        tensors = [None if n is None else d[n] for n in self._slot_names]
+        for tns in tensors:
+            if tns is not None and (not tns.is_cuda or tns.dtype != torch.float32 or not tns.is_contiguous()):
+                raise _lib.TdxError("parameters must be contiguous fp32 CUDA tensors (call .to('cuda'))")
+        return self._ptab_p.get(tensors), tensors
+
+    def _buffer_ptrs(self):
+        d = self._named()
+        tensors = [d[n] for n in self._buf_names]
+        return self._ptab_b.get(tensors), tensors
+
+    def _grad_buffers(self, device):
+        """One flat fp32 gradient buffer with a view per parameter (reference shapes)."""
+        if self._grad_flat is None or self._grad_flat.device != device:
+            d = dict(self.named_parameters())
+            total = sum(d[n].numel() for n in self._param_order)
+            self._grad_flat = torch.zeros(total, dtype=torch.float32, device=device)
+            views, o = {}, 0
+            for n in self._param_order:
+                k = d[n].numel()
+                views[n] = self._grad_flat[o:o + k].view(d[n].shape)
+                o += k
+            self._grad_views = views
+        return self._grad_flat, self._grad_views
+
+    def _mode(self) -> int:
+        if self.training:
+            return MODE_TRAIN
+        return MODE_EVAL_GRAD if torch.is_grad_enabled() else MODE_INFER
+
+    def _check_inputs(self, x, t, y):
+        if not x.is_cuda:
+            raise _lib.TdxError(
+                "tiny_diffusion_amd runs on MI355X only: got a CPU tensor and there is no "
+                "CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
+        if x.dim() != 4 or x.shape[1:] != (1, 28, 28):
+            raise ValueError(f"x must be (B,1,28,28), got {tuple(x.shape)}")
+        if t.shape != (x.shape[0],):
+            raise ValueError("t must have shape (B,)")
+        if (self.num_classes > 0) != (y is not None):
+            raise ValueError("class labels y are required exactly for the conditional model")
+        if y is not None and y.shape != (x.shape[0],):
+            raise ValueError("y must have shape (B,)")
+
+    def _run_forward(self, x, t, y, mode: Optional[int] = None):
+        self._check_inputs(x, t, y)
+        B = x.shape[0]
+        plan = self._plan(B, x.device)
+        mode = self._mode() if mode is None else mode
+        pptr, ptens = self._param_ptrs()
+        bptr, btens = self._buffer_ptrs()
+        x = x.contiguous().float()
+        t = t.contiguous().to(torch.int64)
+        y = None if y is None else y.contiguous().to(torch.int64)
+        out = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        if mode == MODE_INFER:
+            # running statistics are updated by kernels (no torch version bump): _buf_epoch
+            key = tuple(tn._version for tn in ptens if tn is not None) + tuple(tn._version for tn in btens) \
+                + tuple(self._ptab_p.key) + tuple(self._ptab_b.key) + (self._buf_epoch,)
+            if plan.infer_key != key:
+                check(lib.tdx_unet_pack(plan.handle, pptr, bptr, st), "tdx_unet_pack")
+                plan.infer_key = key
+        else:
+            plan.infer_key = None
+            plan.generation += 1
+            if mode == MODE_TRAIN:
+                self._buf_epoch += 1
+        check(lib.tdx_unet_forward(plan.handle, pptr, bptr, x.data_ptr(), t.data_ptr(),
+                                   None if y is None else y.data_ptr(), out.data_ptr(),
+                                   plan.workspace.data_ptr(), plan.ws_bytes, B, mode, st),
+              "tdx_unet_forward")
+        return out, plan, mode
+
+    def _run_backward(self, plan: _Plan, d_out, grad_views, stage_lo: int = 0, stage_hi: Optional[int] = None):
+        pptr, _ = self._param_ptrs()
+        gt = [None if n is None else grad_views[n] for n in self._slot_names]
+        gptr = self._ptab_g.get(gt)
+        nst = lib.tdx_unet_backward_stages()
+        stage_hi = nst if stage_hi is None else stage_hi
+        st = torch.cuda.current_stream(d_out.device).cuda_stream
+        check(lib.tdx_unet_backward(plan.handle, pptr, gptr, d_out.data_ptr(), plan.workspace.data_ptr(),
+                                    plan.ws_bytes, plan.batch, stage_lo, stage_hi, st),
+              "tdx_unet_backward")
+
+    # ------------------------------------------------------------------ forward
+    def _forward_impl(self, x, t, y):
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not needs_grad:
+            return self._run_forward(x, t, y)[0]
+        d = dict(self.named_parameters())
+        params = [d[n] for n in self._param_order]
+        return _UNetFunction.apply(self, x, t, y, *params)
