@@ -106,13 +106,16 @@ int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout
  *   in  (B,H,W,cin)  wpk [cout][9][cin]  bias (cout) or NULL  out (B,H,W,cout)
  * With the dgrad pack and the roles of cin/cout swapped the same entry point
  * computes the input gradient.  cin % 32 == 0, cout % 64 == 0.
- * stats_partial (when TDX_CONV_OUT_STATS): [tdx_conv3x3_stat_tiles(...)][2][cout]. */
+ * stats_partial (when TDX_CONV_OUT_STATS): [tdx_conv3x3_stat_tiles(...)][2][cout] holding,
+ * per tile of tdx_conv3x3_stat_tile_rows(...) output pixels and per channel, the sum
+ * and the sum of squared deviations from the TILE mean (merged by tdx_bn_finalize). */
 int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,
                     int B, int H, int W, int cin, int cout, int flags,
                     const float* in_scale, const float* in_shift,
                     const float* out_scale, const float* out_shift,
                     float* stats_partial, tdx_stream_t stream);
 int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
+int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout);
 
 /* Weight gradient of the same convolution:
  *   dw_slabs[s][cout][9][cin] partial sums over pixel chunk s (split-K, deterministic)
@@ -127,10 +130,12 @@ int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, 
 
 /* BatchNorm2d (diffusion.py:34 ...): turn the conv epilogue's partials into
  * per-channel scale/shift (+ saved mean/rstd) and update the running buffers.
+ * Tile t covers rows [t*tile_rows, min((t+1)*tile_rows, count)); partials are merged
+ * with Chan's parallel-variance formula in double precision.
  *   training != 0: batch statistics (biased var to normalise, unbiased into
  *                  running_var, momentum 0.1, num_batches_tracked += 1)
  *   training == 0: scale/shift from the running statistics. */
-int tdx_bn_finalize(const float* stats_partial, int tiles, int64_t count, int C,
+int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_rows, int64_t count, int C,
                     const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* scale, float* shift, float* save_mean, float* save_rstd,
@@ -216,6 +221,11 @@ int tdx_unet_backward_stages(void);
 int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads,
                       const float* d_out, void* workspace, size_t workspace_bytes,
                       int batch, int stage_lo, int stage_hi, tdx_stream_t stream);
+
+/* Testing aid: offset (in floats) and element count of a named intermediate inside the
+ * workspace after a forward: "x0", "Y0".."Y12", "ss0".."ss12", "e1p", "cat1", "d1a", ... */
+int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, size_t* offset_floats,
+                    size_t* numel);
 
 /* Pack conv weights + fold nothing: refreshes the plan's device-side packed
  * copies from `params`.  Called by forward automatically in TRAIN/EVAL_GRAD;

@@ -93,17 +93,34 @@ def batchnorm2d(x, weight, bias, running_mean, running_var, training, nbt=None):
     )
 
 
-def maxpool2_ceil(x):
-    """nn.MaxPool2d(2, ceil_mode=True) (diffusion.py:101): 2x2/stride 2; the
-    last window of an odd extent holds a single valid row/column (7 -> 4)."""
+def pool_windows(x):
+    """(n,c,h,w) -> (n,c,ho,wo,4) windows in ATen scan order, -inf padded (ceil mode)."""
     n, c, h, w = x.shape
     ho, wo = (h + 1) // 2, (w + 1) // 2
     xp = F.pad(x, (0, 2 * wo - w, 0, 2 * ho - h), value=float("-inf"))
-    xp = xp.view(n, c, ho, 2, wo, 2)
-    return xp.amax(dim=(3, 5))
+    return xp.view(n, c, ho, 2, wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, ho, wo, 4)
 
 
-def _ac_axis(n_in: int, n_out: int):
+def maxpool2_ceil(x, idx=None):
+    """nn.MaxPool2d(2, ceil_mode=True) (diffusion.py:101): 2x2/stride 2; the
+    last window of an odd extent holds a single valid row/column (7 -> 4).
+
+    Backward semantics matter: ATen routes the whole gradient to the FIRST maximum
+    of a window in scan order (`val > maxval`), it does not split it among ties.
+    argmax returns the first maximal index; gather's backward routes to exactly
+    that element.
+
+    ``idx`` (n,c,ho,wo,1) overrides the arg-max: tests use it to evaluate the oracle
+    with the SAME routing decisions as the implementation under test - two window
+    entries that agree to ~1e-6 are a coin flip in fp32, and either choice is a
+    valid sub-gradient."""
+    win = pool_windows(x)
+    if idx is None:
+        idx = win.detach().argmax(dim=-1, keepdim=True)
+    return torch.gather(win, -1, idx).squeeze(-1)
+
+
+def _ac_axis(n_in: int, n_out: int, dtype=torch.float32):
     """align_corners=True source coordinates for one axis, fp32 like ATen:
     scale = (in-1)/(out-1); src = scale*dst; i0 = floor(src); lam = src-i0."""
     if n_out > 1:
@@ -116,15 +133,15 @@ def _ac_axis(n_in: int, n_out: int):
     i1 = (i0 + 1).clamp_(max=n_in - 1)
     lam1 = src - i0.to(torch.float32)
     lam0 = 1.0 - lam1
-    return i0, i1, lam0, lam1
+    return i0, i1, lam0.to(dtype), lam1.to(dtype)
 
 
 def bilinear_ac(x, size):
     """F.interpolate(mode='bilinear', align_corners=True) / nn.Upsample(2x)
     (diffusion.py:102, 135-159), NCHW."""
     ho, wo = size
-    h0, h1, hl0, hl1 = _ac_axis(x.shape[2], ho)
-    w0, w1, wl0, wl1 = _ac_axis(x.shape[3], wo)
+    h0, h1, hl0, hl1 = _ac_axis(x.shape[2], ho, x.dtype)
+    w0, w1, wl0, wl1 = _ac_axis(x.shape[3], wo, x.dtype)
     top = x[:, :, h0, :]
     bot = x[:, :, h1, :]
     wl0 = wl0.view(1, 1, 1, -1)
@@ -157,7 +174,9 @@ def stage(x, p, name, training, buffers):
 def time_embedding(p, t, y=None):
     """diffusion.py:111-113 (+ conditional_diffusion.py:121-125): raw integer t
     cast to float, Linear(1,256) -> SiLU -> Linear(256,256), plus E[y]."""
-    tf = t.unsqueeze(-1).float()
+    # .float() in the reference; the weights' dtype here so that the same code also
+    # runs as the fp64 ground truth used to calibrate gradient tolerances
+    tf = t.unsqueeze(-1).to(p["time_embedding.0.weight"].dtype)
     h = F.linear(tf, p["time_embedding.0.weight"], p["time_embedding.0.bias"])
     h = h * torch.sigmoid(h)
     emb = F.linear(h, p["time_embedding.2.weight"], p["time_embedding.2.bias"])
@@ -178,7 +197,7 @@ def split_state(sd):
     return params, buffers
 
 
-def unet_forward(p, buffers, x, t, y=None, training=False, taps=None):
+def unet_forward(p, buffers, x, t, y=None, training=False, taps=None, pool_idx=None):
     """NoiseModel.forward, diffusion.py:109-162 / conditional_diffusion.py:115-172.
 
     ``p``: parameter dict; ``buffers``: BN buffers (updated in place when
@@ -193,11 +212,12 @@ def unet_forward(p, buffers, x, t, y=None, training=False, taps=None):
     emb = tap("emb", time_embedding(p, t, y))
     x0 = tap("x0", F.conv2d(x, p["initial_conv.weight"], p["initial_conv.bias"], padding=1))
     e1 = tap("e1", stage(x0, p, "enc1", training, buffers))
-    e1p = tap("e1p", maxpool2_ceil(e1))
+    pool_idx = pool_idx or {}
+    e1p = tap("e1p", maxpool2_ceil(e1, pool_idx.get("e1")))
     e2 = tap("e2", stage(e1p, p, "enc2", training, buffers))
-    e2p = tap("e2p", maxpool2_ceil(e2))
+    e2p = tap("e2p", maxpool2_ceil(e2, pool_idx.get("e2")))
     e3 = tap("e3", stage(e2p, p, "enc3", training, buffers))
-    e3p = tap("e3p", maxpool2_ceil(e3))
+    e3p = tap("e3p", maxpool2_ceil(e3, pool_idx.get("e3")))
     b = tap("b", conv_bn_relu(e3p, p, "bottleneck.0", "bottleneck.1", training, buffers))
 
     # 1x1 conv on a (B,256,1,1) map == linear, diffusion.py:130-132
@@ -223,13 +243,21 @@ def unet_forward(p, buffers, x, t, y=None, training=False, taps=None):
     return tap("out", out)
 
 
-def train_step_grads(sd, x_t, t, noise, y=None, training=True):
+def train_step_grads(sd, x_t, t, noise, y=None, training=True, dtype=torch.float32, pool_idx=None,
+                     taps=None):
     """Forward + MSE + backward (diffusion.py:228-235) on the oracle.
 
-    Returns (loss, eps_hat, grads dict, updated buffers)."""
+    Returns (loss, eps_hat, grads dict, updated buffers).  ``dtype=torch.float64``
+    evaluates the same graph in double precision (ground truth for tolerances:
+    train-mode BatchNorm over a near-dead channel amplifies fp32 rounding noise
+    by up to 1/sqrt(eps) ~ 300x, in the reference just the same)."""
     params, buffers = split_state(sd)
+    if dtype != torch.float32:
+        params = OrderedDict((k, v.to(dtype)) for k, v in params.items())
+        buffers = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v) for k, v in buffers.items())
+        x_t, noise = x_t.to(dtype), noise.to(dtype)
     leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
-    eps_hat = unet_forward(leaves, buffers, x_t, t, y, training=training)
+    eps_hat = unet_forward(leaves, buffers, x_t, t, y, training=training, taps=taps, pool_idx=pool_idx)
     loss = F.mse_loss(eps_hat, noise)
     grads = torch.autograd.grad(loss, list(leaves.values()))
     return loss.detach(), eps_hat.detach(), OrderedDict(zip(leaves.keys(), grads)), buffers

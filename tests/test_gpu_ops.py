@@ -23,8 +23,19 @@ def tdx():
     return L
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.cuda().contiguous()
+    """Copy to the GPU and keep the tensor alive: a temporary whose only use is
+    ``.data_ptr()`` would be freed (and its block re-used by the next temporary)
+    before the kernel that reads it has even been launched."""
+    d = t.cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return d
 
 
 def nhwc(t):
@@ -55,16 +66,25 @@ def test_q_sample_bit_exact(tdx, golden_dir):
     from tiny_diffusion_amd.diffusion import ForwardProcess
 
     fp = ForwardProcess()
-    x_t, noise = fp.q_sample("cuda", torch.from_numpy(d["x0"]).cuda(), torch.from_numpy(d["t"]).cuda(),
-                             noise=torch.from_numpy(d["noise"]).cuda())
-    assert torch.equal(x_t.cpu(), torch.from_numpy(d["x_t"]))  # bit-exact vs the reference's own x_t
-    # schedule tables are the reference's
+    x0, t, noise = torch.from_numpy(d["x0"]), torch.from_numpy(d["t"]), torch.from_numpy(d["noise"])
+    x_t, noise_out = fp.q_sample("cuda", x0.cuda(), t.cuda(), noise=noise.cuda())
+    assert torch.equal(noise_out.cpu(), noise)
+    # bit-exact against the oracle evaluated on THIS host (the schedule tables are host
+    # fp32 arithmetic - linspace/cumprod/sqrt - whose last bit can depend on the CPU's
+    # vector ISA, in the reference just the same)
+    ref_here = R.q_sample(R.Schedule(), x0, t, noise)
+    nbad = int((x_t.cpu() != ref_here).sum())
+    assert nbad == 0, (nbad, (x_t.cpu() - ref_here).abs().max().item())
+    # and within 2 ulp of the x_t the reference produced in the build container
+    ref = torch.from_numpy(d["x_t"])
+    assert (x_t.cpu() - ref).abs().max().item() <= 1e-6
     s = np.load(os.path.join(golden_dir, "schedule.npz"))
-    assert np.array_equal(fp.alphas_cumprod.numpy(), s["alphas_cumprod"])
+    assert np.allclose(fp.alphas_cumprod.numpy(), s["alphas_cumprod"], rtol=1e-6, atol=0)
     sa, sb, coef = fp.tables("cuda")
-    assert np.array_equal(coef.cpu().numpy()[:, 0], s["c1"])
-    assert np.array_equal(coef.cpu().numpy()[:, 1], s["c2"])
-    assert np.array_equal(coef.cpu().numpy()[:, 2], s["sigma"])
+    c1, c2, sig = R.Schedule().p_sample_coeffs()
+    assert torch.equal(coef.cpu(), torch.stack([c1, c2, sig], 1))
+    print("schedule bit-identical to the build container's:",
+          np.array_equal(fp.alphas_cumprod.numpy(), s["alphas_cumprod"]))
 
 
 def test_q_sample_philox_statistics(tdx):
@@ -141,9 +161,13 @@ def test_conv3x3_fwd_plain_and_stats(tdx, B, H, cin, cout):
                                       cin, cout, 4, None, None, None, None, stats.data_ptr(), stream()))
     torch.cuda.synchronize()
     assert rel_err(nchw(out), ref) < 2e-6
-    s = stats.double().sum(0).cpu()
-    assert torch.allclose(s[0], ref.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(s[1], ref.double().pow(2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    # per-tile (sum, M2 about the tile mean) partials
+    rows = tdx.lib.tdx_conv3x3_stat_tile_rows(B, H, H, cin, cout)
+    flat = nhwc(ref).reshape(-1, cout).double()
+    for ti in range(tiles):
+        blk = flat[ti * rows:(ti + 1) * rows]
+        assert torch.allclose(stats[ti, 0].double().cpu(), blk.sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(stats[ti, 1].double().cpu(), (blk - blk.mean(0)).pow(2).sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("B,H,cin,cout", [(3, 14, 128, 256), (2, 32, 64, 64), (5, 7, 512, 512)])
@@ -209,7 +233,8 @@ def test_bn_finalize_and_backward(tdx, training):
     """BatchNorm2d train/eval forward statistics + BN/ReLU backward vs autograd."""
     B, H, Cc = 6, 14, 128
     g = torch.Generator().manual_seed(11)
-    y = torch.randn(B, Cc, H, H, generator=g) * 2 + 0.5
+    # large per-channel offsets: E[y^2]-E[y]^2 would lose ~4 digits here
+    y = torch.randn(B, Cc, H, H, generator=g) * 0.3 + 30.0 * torch.randn(1, Cc, 1, 1, generator=g)
     gamma = (1 + 0.1 * torch.randn(Cc, generator=g)).requires_grad_(True)
     beta = (0.1 * torch.randn(Cc, generator=g)).requires_grad_(True)
     rm, rv = torch.randn(Cc, generator=g) * 0.1, 1 + torch.rand(Cc, generator=g)
@@ -222,18 +247,21 @@ def test_bn_finalize_and_backward(tdx, training):
     # ---- device
     yd = dev(nhwc(y))
     rows = B * H * H
-    # emulate the conv epilogue partials with 3 uneven tiles
-    cuts = [0, 100, 700, rows]
+    # emulate the conv epilogue partials: tiles of 500 rows (last one ragged)
+    tile_rows = 500
+    ntile = (rows + tile_rows - 1) // tile_rows
     y2 = yd.view(rows, Cc).double()
-    stats = torch.stack([torch.stack([y2[cuts[i]:cuts[i + 1]].sum(0), y2[cuts[i]:cuts[i + 1]].pow(2).sum(0)])
-                         for i in range(3)]).float().contiguous()
+    stats = torch.stack([torch.stack([blk.sum(0), (blk - blk.mean(0)).pow(2).sum(0)])
+                         for blk in y2.split(tile_rows)]).float().contiguous()
     sc, sh, mu, rs = (torch.empty(Cc, device="cuda") for _ in range(4))
     rmd, rvd, nbtd = dev(rm), dev(rv), nbt.cuda()
-    tdx.check(tdx.lib.tdx_bn_finalize(stats.data_ptr(), 3, rows, Cc, dev(gamma.detach()).data_ptr(),
+    tdx.check(tdx.lib.tdx_bn_finalize(stats.data_ptr(), ntile, tile_rows, rows, Cc, dev(gamma.detach()).data_ptr(),
                                       dev(beta.detach()).data_ptr(), rmd.data_ptr(), rvd.data_ptr(), nbtd.data_ptr(),
                                       sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), training, stream()))
     act = F.relu(yd * sc + sh)
-    assert rel_err(nchw(act), a.detach()) < 2e-6
+    # y*scale+shift (ATen's own CPU form) cancels |mean|*scale against the result: with the
+    # |mean|/std ~ 100 of this test that costs ~2 digits relative to (y-mean)*rstd*w+b
+    assert rel_err(nchw(act), a.detach()) < 2e-5
     if training:
         assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
         assert torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
@@ -247,9 +275,10 @@ def test_bn_finalize_and_backward(tdx, training):
     tdx.check(tdx.lib.tdx_bn_relu_bwd(gd.data_ptr(), yd.data_ptr(), rows, Cc, sc.data_ptr(), sh.data_ptr(),
                                       mu.data_ptr(), rs.data_ptr(), dev(gamma.detach()).data_ptr(), dg.data_ptr(),
                                       db.data_ptr(), dbias.data_ptr(), scr.data_ptr(), training, stream()))
-    assert rel_err(nchw(gd), yy.grad) < 5e-6
-    assert rel_err(dg, gamma.grad) < 5e-6
-    assert rel_err(db, beta.grad) < 5e-6
+    # (|mean|/std ~ 100 in this test: xhat carries ~1e-5 relative rounding on both sides)
+    assert rel_err(nchw(gd), yy.grad) < 2e-5
+    assert rel_err(dg, gamma.grad) < 2e-5
+    assert rel_err(db, beta.grad) < 2e-5
     ref_dbias = yy.grad.sum((0, 2, 3))
     if training:
         assert dbias.abs().max().item() == 0.0 and ref_dbias.abs().max().item() < 1e-3

@@ -124,6 +124,8 @@ def test_backward_matches_reference_golden(golden_dir, name, cond):
     loss.backward()
     assert abs(loss.item() - float(d["loss"])) <= 2e-5 * float(d["loss"])
     assert rel_mse(eps.detach(), torch.from_numpy(d["eps_hat"])) < REL_MSE_TOL
+    # (1) against the numbers the reference itself produced (loose: these gradients carry
+    #     fp32 rounding noise amplified by train-mode BN, see _grad_tolerances)
     bad = []
     for k, p in m.named_parameters():
         kk = k.replace(".", "__")
@@ -139,9 +141,18 @@ def test_backward_matches_reference_golden(golden_dir, name, cond):
         e_norm = abs(got.double().norm().item() - gn) / gn
         rms = gn / np.sqrt(got.numel())
         e_head = (got[: head.numel()] - head).abs().max().item() / max(head.abs().max().item(), rms)
-        e_sum = abs(got.double().sum().item() - float(d[f"gsum__{kk}"])) / (gn * np.sqrt(got.numel()))
-        if e_norm > 5e-4 or e_head > 5e-3 or e_sum > 1e-3:
-            bad.append((k, e_norm, e_head, e_sum))
+        if e_norm > 2e-3 or e_head > 3e-2:
+            bad.append((k, e_norm, e_head))
+    assert not bad, bad
+    # (2) precision: as close to the exact (fp64) gradient as the fp32 CPU oracle is,
+    #     both evaluated with the max-pool routing the GPU chose
+    y_cpu = torch.from_numpy(d["y"]) if cond else None
+    sd0 = make_state_dict(int(d["seed"]), cond)
+    cpu_args = (sd0, torch.from_numpy(d["x_t"]), torch.from_numpy(d["t"]), torch.from_numpy(d["noise"]), y_cpu)
+    pidx = _gpu_pool_routing(m, x_t.shape[0], cpu_args)
+    _, _, g32, _ = R.train_step_grads(*cpu_args, pool_idx=pidx)
+    _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, pool_idx=pidx)
+    bad = _grad_precision_failures({k: p.grad for k, p in m.named_parameters()}, g32, g64, True)
     assert not bad, bad
     for k, v in m.state_dict().items():
         if "running_" in k:
@@ -158,33 +169,84 @@ def test_backward_matches_reference_golden(golden_dir, name, cond):
         assert bool(((got - head).abs() <= tol).all()), k
 
 
+def _gpu_pool_routing(m, B, cpu_args, training=True):
+    """Arg-max index of every max-pool window as the GPU forward decided it (from its own
+    pre-BN tensors and scale/shift), checked against the exact routing: they may differ
+    only where the two largest entries of a window agree to 1e-4 (an fp32 coin flip,
+    either choice being a valid sub-gradient of max)."""
+    plan = [p for (dev, b), p in m._plans.items() if b == B][0]
+    taps = {}
+    sd, x, t, noise, y = cpu_args
+    p64, b64 = R.split_state(sd)
+    p64 = {k: v.double() for k, v in p64.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in b64.items()}
+    with torch.no_grad():
+        R.unet_forward(p64, b64, x.double(), t, y, training=training, taps=taps)
+    out = {}
+    for name, unit, H, Cc in (("e1", 1, 28, 128), ("e2", 3, 14, 256), ("e3", 5, 7, 512)):
+        Y = plan.tensor(f"Y{unit}").view(B, H, H, Cc)
+        ss = plan.tensor(f"ss{unit}")
+        a = torch.relu(torch.addcmul(ss[Cc:2 * Cc], Y, ss[:Cc])).permute(0, 3, 1, 2).cpu()
+        win = R.pool_windows(a)
+        idx = win.argmax(dim=-1, keepdim=True)
+        w64 = R.pool_windows(taps[name])
+        idx64 = w64.argmax(dim=-1, keepdim=True)
+        differ = (idx != idx64).squeeze(-1)
+        if differ.any():
+            top2 = w64[differ].topk(2, dim=-1).values
+            gap = ((top2[:, 0] - top2[:, 1]) / top2[:, 0].abs().clamp_min(1e-30))
+            assert gap.max().item() < 1e-4, (name, int(differ.sum()), gap.max().item())
+        out[name] = idx
+    return out
+
+
+def _grad_precision_failures(got, g32, g64, training, k_factor=10.0, floor=1e-4):
+    """Per-parameter: ||g_gpu - g64|| / ||g64|| must be within k_factor x the fp32 CPU
+    oracle's own distance from the fp64 ground truth (floor 1e-4: an fp32 MFMA dot product
+    is one sequential fma chain, error ~sqrt(K) eps of sum|a*b|, and weight gradients
+    cancel heavily - observed worst case 6e-5 on enc1.0.weight in eval mode).  A train-mode
+    BatchNorm over a nearly constant channel multiplies rounding noise by up to
+    1/sqrt(eps) ~ 300; that noise is a property of fp32 evaluation of this network
+    (the reference has it too), so the bound is calibrated per case, not fixed."""
+    errs_cpu = {}
+    for k in g64:
+        n64 = g64[k].norm().item()
+        errs_cpu[k] = (g32[k].double() - g64[k]).norm().item() / max(n64, 1e-30)
+    usable = [e for k, e in errs_cpu.items() if not (training and is_pre_bn_bias(k))]
+    med = float(np.median(usable))
+    bad = []
+    for k, g in got.items():
+        if training and is_pre_bn_bias(k):
+            continue  # exactly-zero true gradient: both sides are pure rounding noise
+        n64 = g64[k].norm().item()
+        err = (g.detach().double().cpu() - g64[k]).norm().item() / max(n64, 1e-30)
+        tol = max(k_factor * errs_cpu[k], k_factor * med, floor)
+        if not err <= tol:
+            bad.append((k, f"gpu {err:.2e}", f"cpu32 {errs_cpu[k]:.2e}", f"tol {tol:.2e}"))
+    return bad
+
+
 def test_backward_vs_oracle_full_tensors():
-    """Every element of every gradient against the oracle's autograd (small batch),
-    train mode and eval mode (the unconditional script trains with BN in eval mode
-    after its first sample() call - SURVEY.md 3.1)."""
-    for cond, B, training in ((False, 6, True), (True, 4, True), (False, 5, False)):
+    """Every element of every gradient against the oracle (small batches), train mode
+    and eval mode (the unconditional script trains with BN in eval mode after its first
+    sample() call - SURVEY.md 3.1)."""
+    for cond, B, training in ((True, 4, True), (False, 6, True), (False, 5, False), (True, 3, False)):
         sd = make_state_dict(2, cond)
         g = torch.Generator().manual_seed(17 + B)
         x = torch.randn(B, 1, 28, 28, generator=g)
         noise = torch.randn(B, 1, 28, 28, generator=g)
         t = torch.randint(0, 1000, (B,), generator=g)
         y = torch.randint(0, 10, (B,), generator=g) if cond else None
-        loss_ref, eps_ref, grads_ref, bufs = R.train_step_grads(sd, x, t, noise, y, training=training)
         m = build(cond, 2)
         m.train(training)
         eps = m(x.cuda(), t.cuda(), y.cuda()) if cond else m(x.cuda(), t.cuda())
         loss = F.mse_loss(eps, noise.cuda())
         loss.backward()
+        pidx = _gpu_pool_routing(m, B, (sd, x, t, noise, y), training)
+        loss_ref, eps_ref, g32, bufs = R.train_step_grads(sd, x, t, noise, y, training=training, pool_idx=pidx)
+        _, _, g64, _ = R.train_step_grads(sd, x, t, noise, y, training=training, dtype=torch.float64, pool_idx=pidx)
         assert abs(loss.item() - loss_ref.item()) < 2e-5 * loss_ref.item()
-        bad = []
-        for k, p in m.named_parameters():
-            ref = grads_ref[k]
-            got = p.grad.cpu()
-            if is_pre_bn_bias(k) and training:
-                continue
-            err = (got.double() - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-30)
-            if err > 2e-4:
-                bad.append((k, err))
+        bad = _grad_precision_failures({k: p.grad for k, p in m.named_parameters()}, g32, g64, training)
         assert not bad, (cond, B, training, bad)
 
 

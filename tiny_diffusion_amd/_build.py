@@ -44,8 +44,21 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _flags_stamp():
+    return " ".join(HIPCC_FLAGS)
+
+
+def _stamp_matches():
+    try:
+        return open(os.path.join(OBJDIR, "flags.txt")).read() == _flags_stamp()
+    except OSError:
+        return False
+
+
 def is_stale():
     if not os.path.exists(LIB):
+        return True
+    if os.path.isdir(OBJDIR) and not _stamp_matches():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(s) > t for s in sources()) or _deps_mtime() > t
@@ -58,6 +71,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_t = _deps_mtime()
+    if not _stamp_matches():
+        force = True  # objects were built with other flags
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
@@ -82,6 +97,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)
+    with open(os.path.join(OBJDIR, "flags.txt"), "w") as f:
+        f.write(_flags_stamp())
     return LIB
 
 

@@ -64,11 +64,12 @@ _SIGS = {
     "tdx_conv3x3_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_stat_tile_rows": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _ptr, _ptr, _ptr]),
     "tdx_conv3x3_wgrad_reduce": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, _ptr]),
-    "tdx_bn_finalize": (C.c_int, [_ptr, C.c_int, C.c_int64, C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr,
+    "tdx_bn_finalize": (C.c_int, [_ptr, C.c_int, C.c_int, C.c_int64, C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                   _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
     "tdx_bn_relu_bwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                   _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
@@ -89,6 +90,7 @@ _SIGS = {
     "tdx_unet_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     _ptr]),
     "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
+    "tdx_unet_tensor": (C.c_int, [_ptr, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tdx_probe_mfma_f32": (C.c_int, [_ptr, C.c_int, C.c_int, _ptr]),
     "tdx_probe_stream_copy": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
 }

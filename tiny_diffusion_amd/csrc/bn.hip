@@ -9,32 +9,49 @@
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
 
-// block = 256 threads = 32 channels x 8 slices of the tile list; double accumulation
+// Merge per-tile (sum, M2-about-the-tile-mean) partials with Chan's parallel-variance
+// formula in double.  block = 256 threads = 32 channels x 8 slices of the tile list.
+struct Moments {
+  double n, mean, m2;
+};
+__device__ static inline void chan_merge(Moments& a, double nb, double meanb, double m2b) {
+  if (nb <= 0.0) return;
+  const double n = a.n + nb;
+  const double delta = meanb - a.mean;
+  a.m2 += m2b + delta * delta * (a.n * nb / n);
+  a.mean += delta * (nb / n);
+  a.n = n;
+}
+
 __global__ void __launch_bounds__(256)
-bn_finalize_kernel(const float* __restrict__ stats, int tiles, double count, int C,
+bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t count, int C,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* __restrict__ rmean, float* __restrict__ rvar,
                    int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ save_mean, float* __restrict__ save_rstd, int training) {
-  __shared__ double red[2][8][32];
+  __shared__ double red[3][8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   if (training) {
-    double s = 0.0, q = 0.0;
+    Moments m = {0.0, 0.0, 0.0};
     if (c < C)
       for (int t = sl; t < tiles; t += 8) {
-        s += (double)stats[((size_t)t * 2 + 0) * C + c];
-        q += (double)stats[((size_t)t * 2 + 1) * C + c];
+        const int64_t r0 = (int64_t)t * tile_rows;
+        const double nt = (double)(r0 + tile_rows <= count ? tile_rows : count - r0);
+        const double st = (double)stats[((size_t)t * 2 + 0) * C + c];
+        const double qt = (double)stats[((size_t)t * 2 + 1) * C + c];
+        chan_merge(m, nt, st / nt, qt);
       }
-    red[0][sl][cl] = s;
-    red[1][sl][cl] = q;
+    red[0][sl][cl] = m.n;
+    red[1][sl][cl] = m.mean;
+    red[2][sl][cl] = m.m2;
     __syncthreads();
     if (sl == 0 && c < C) {
-      s = 0.0; q = 0.0;
-      for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
-      const double mean = s / count;
-      double var = q / count - mean * mean;  // biased, used to normalise
-      if (var < 0.0) var = 0.0;
+      Moments a = {0.0, 0.0, 0.0};
+      for (int k = 0; k < 8; ++k) chan_merge(a, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
+      const double n = (double)count;
+      const double mean = a.mean;
+      const double var = a.m2 / n;  // biased, used to normalise
       const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
       const float sc = gamma[c] * rstd;
       scale[c] = sc;
@@ -42,7 +59,7 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, double count, int
       if (save_mean) save_mean[c] = (float)mean;
       if (save_rstd) save_rstd[c] = rstd;
       if (rmean) {
-        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        const double unbiased = n > 1.0 ? a.m2 / (n - 1.0) : var;
         rmean[c] = (1.0f - BN_MOMENTUM) * rmean[c] + BN_MOMENTUM * (float)mean;
         rvar[c] = (1.0f - BN_MOMENTUM) * rvar[c] + BN_MOMENTUM * (float)unbiased;
       }
@@ -59,16 +76,18 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, double count, int
   }
 }
 
-extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int64_t count, int C,
-                               const float* gamma, const float* beta, float* running_mean,
+extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_rows, int64_t count,
+                               int C, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* scale,
                                float* shift, float* save_mean, float* save_rstd, int training,
                                tdx_stream_t stream) {
   if (!gamma || !beta || !scale || !shift || C <= 0) return TDX_E_BADARG;
-  if (training && (!stats_partial || tiles <= 0 || count <= 0)) return TDX_E_BADARG;
+  if (training && (!stats_partial || tiles <= 0 || tile_rows <= 0 || count <= 0)) return TDX_E_BADARG;
+  if (training && ((int64_t)tiles * tile_rows < count || (int64_t)(tiles - 1) * tile_rows >= count))
+    return TDX_E_BADARG;
   if (!training && (!running_mean || !running_var)) return TDX_E_BADARG;
   bn_finalize_kernel<<<cdiv(C, 32), 256, 0, to_stream(stream)>>>(
-      stats_partial, tiles, (double)count, C, gamma, beta, running_mean, running_var,
+      stats_partial, tiles, tile_rows, count, C, gamma, beta, running_mean, running_var,
       num_batches_tracked, scale, shift, save_mean, save_rstd, training);
   TDX_CHECK_LAUNCH();
   return 0;

@@ -166,7 +166,7 @@ conv3x3_igemm_kernel(ConvArgs a) {
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
   //      row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  float csum[TN], csq[TN];
+  float csum[TN];
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
     const int col = n0 + wn * WTN + in * 32 + l31;
@@ -176,7 +176,7 @@ conv3x3_igemm_kernel(ConvArgs a) {
       osc = a.out_scale[col];
       osh = a.out_shift[col];
     }
-    float s = 0.f, q = 0.f;
+    float s = 0.f;
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
 #pragma unroll
@@ -185,35 +185,65 @@ conv3x3_igemm_kernel(ConvArgs a) {
         const int p = m0 + row;
         float v = acc[im][in][r] + bv;
         if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
+        acc[im][in][r] = v;
         if (p < a.M) {
           a.out[(size_t)p * a.Cout + col] = v;
           s += v;
-          q += v * v;
         }
       }
     }
     csum[in] = s;
-    csq[in] = q;
   }
   if (EPI == EPI_STATS) {
-    // column sums: lane halves -> waves sharing the column range -> one row of partials
-    float* red = smem;  // [WGM][2][BN], re-uses the tile buffers (all waves are past the K loop)
+    // BatchNorm statistics of this tile, per output channel: (sum, M2) with M2 centred on
+    // the TILE mean (two reductions over the accumulators, which are still in registers).
+    // Centred partials are merged with Chan's formula in bn_finalize, so the variance never
+    // sees the E[y^2]-E[y]^2 cancellation.
+    float* red = smem;  // [WGM][BN] + [BN] means, re-uses the tile buffers (K loop is over)
+    const int rows_valid = min(BM, a.M - m0);
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      float s = csum[in] + __shfl_xor(csum[in], 32, 64);
-      float q = csq[in] + __shfl_xor(csq[in], 32, 64);
-      if (half == 0) {
-        red[(wm * 2 + 0) * BN + wn * WTN + in * 32 + l31] = s;
-        red[(wm * 2 + 1) * BN + wn * WTN + in * 32 + l31] = q;
-      }
+      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int which = i / BN, c = i - which * BN;
+    float* tsum = red + WGM * BN;   // [BN] tile column sums
+    for (int c = tid; c < BN; c += 256) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[(w * 2 + which) * BN + c];
-      a.stats[((size_t)tile_m * 2 + which) * a.Cout + n0 + c] = v;
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      tsum[c] = v;
+      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)rows_valid;
+    float cm2[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m0 + row < a.M) {
+            const float dlt = acc[im][in][r] - mean;
+            q = fmaf(dlt, dlt, q);
+          }
+        }
+      cm2[in] = q + __shfl_xor(q, 32, 64);
+    }
+    __syncthreads();  // everyone has read tsum/red
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
     }
   }
 }
@@ -271,6 +301,11 @@ extern "C" int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout) {
   (void)cin;
   int64_t M = (int64_t)B * H * W;
   return cdiv(M, pick_tile(M, cout).bm);
+}
+
+extern "C" int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout) {
+  (void)cin;
+  return pick_tile((int64_t)B * H * W, cout).bm;
 }
 
 extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,

@@ -16,6 +16,8 @@
 #include "internal.h"
 #include <algorithm>
 #include <new>
+#include <string>
+#include <cstdlib>
 
 namespace {
 
@@ -133,6 +135,43 @@ extern "C" size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mod
 
 extern "C" int tdx_unet_backward_stages(void) { return N_STAGES; }
 
+// Where a named intermediate lives inside the workspace (testing / debugging aid):
+// "x0", "Y0".."Y12" (pre-BN conv outputs; post-activation in INFER mode), "ss0".."ss12"
+// (scale|shift|mean|rstd), "e1p" "e2p" "e3p" "cat3" "cat2" "cat1" "d1a" "emb" "t1" "t2" "t3",
+// "G1" "G2" "GS1" "GS2" "GS3".
+extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, size_t* offset_floats,
+                               size_t* numel) {
+  if (!u || !name || !offset_floats || !numel || batch <= 0 || batch > u->max_batch) return TDX_E_BADARG;
+  const Layout L = make_layout(batch);
+  const size_t b = (size_t)batch;
+  std::string n(name);
+  auto unit_index = [&](const std::string& s, size_t prefix) -> int {
+    if (s.size() <= prefix) return -1;
+    int v = atoi(s.c_str() + prefix);
+    return (v >= 0 && v < 13) ? v : -1;
+  };
+  struct { const char* nm; size_t off, cnt; } fixed[] = {
+      {"x0", L.x0, b * 784 * 64}, {"e1p", L.e1p, b * 196 * 128}, {"e2p", L.e2p, b * 49 * 256},
+      {"e3p", L.e3p, b * 16 * 512}, {"cat3", L.cat3, b * 64 * 1024}, {"cat2", L.cat2, b * 256 * 512},
+      {"cat1", L.cat1, b * 1024 * 256}, {"d1a", L.d1a, b * 784 * 64}, {"emb", L.emb, b * TD},
+      {"t1", L.t1, b * 128}, {"t2", L.t2, b * 256}, {"t3", L.t3, b * 512},
+      {"G1", L.G1, b * 1024 * 256}, {"G2", L.G2, b * 1024 * 256}, {"GS1", L.GS1, b * 784 * 128},
+      {"GS2", L.GS2, b * 196 * 256}, {"GS3", L.GS3, b * 49 * 512}};
+  for (auto& f : fixed)
+    if (n == f.nm) { *offset_floats = f.off; *numel = f.cnt; return 0; }
+  if (n.rfind("ss", 0) == 0) {
+    int i = unit_index(n, 2);
+    if (i < 0) return TDX_E_BADARG;
+    *offset_floats = L.ss[i]; *numel = 4 * (size_t)UNITS[i].cout; return 0;
+  }
+  if (n[0] == 'Y') {
+    int i = unit_index(n, 1);
+    if (i < 0) return TDX_E_BADARG;
+    *offset_floats = L.Y[i]; *numel = b * UNITS[i].hw * UNITS[i].hw * UNITS[i].cout; return 0;
+  }
+  return TDX_E_BADARG;
+}
+
 // weights always; the INFER-mode scale/shift (from the running statistics) only when
 // `buffers` is given
 static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffers,
@@ -144,7 +183,7 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     if (rc) return rc;
     if (buffers) {
       float* ss = u->infer_ss + u->iss_off[i];
-      rc = tdx_bn_finalize(nullptr, 0, 0, UNITS[i].cout, P[TDX_P_UNIT0 + 4 * i + 2],
+      rc = tdx_bn_finalize(nullptr, 0, 0, 0, UNITS[i].cout, P[TDX_P_UNIT0 + 4 * i + 2],
                            P[TDX_P_UNIT0 + 4 * i + 3], (float*)buffers[3 * i],
                            (float*)buffers[3 * i + 1], nullptr, ss, ss + UNITS[i].cout, nullptr,
                            nullptr, 0, stream);
@@ -216,7 +255,9 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
                        d.in_bn ? sc(i - 1) : nullptr, d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr,
                        ws + L.stats, stream));
     const int tiles = tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout);
-    return tdx_bn_finalize(ws + L.stats, tiles, (int64_t)B * d.hw * d.hw, d.cout,
+    return tdx_bn_finalize(ws + L.stats, tiles,
+                           tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout),
+                           (int64_t)B * d.hw * d.hw, d.cout,
                            P[TDX_P_UNIT0 + 4 * i + 2], P[TDX_P_UNIT0 + 4 * i + 3],
                            (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
                            (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout,

@@ -96,6 +96,13 @@ class _Plan:
         self.generation = 0      # bumped by every forward that saves state
         self.infer_key = None    # parameter versions the INFER pack was built from
 
+    def tensor(self, name: str) -> torch.Tensor:
+        """View of a named intermediate inside the workspace (tests / debugging)."""
+        off, cnt = C.c_size_t(), C.c_size_t()
+        check(lib.tdx_unet_tensor(self.handle, self.batch, name.encode(), C.byref(off), C.byref(cnt)),
+              f"tdx_unet_tensor({name})")
+        return self.workspace.view(torch.float32)[off.value:off.value + cnt.value]
+
     def __del__(self):
         try:
             if self.handle:
@@ -123,8 +130,9 @@ class _UNetFunction(torch.autograd.Function):
     """eps_hat = UNet(x, t[, y]); backward returns every parameter gradient."""
 
     @staticmethod
-    def forward(ctx, module, x, t, y, *params):
-        out, plan, mode = module._run_forward(x, t, y)
+    def forward(ctx, module, mode, x, t, y, *params):
+        # grad mode is off inside Function.forward, so the caller decides the mode
+        out, plan, mode = module._run_forward(x, t, y, mode=mode)
         ctx.module = module
         ctx.plan = plan
         ctx.generation = plan.generation
@@ -142,7 +150,7 @@ class _UNetFunction(torch.autograd.Function):
         flat, views = module._grad_buffers(d_out.device)
         module._run_backward(plan, d_out.contiguous(), views)
         grads = tuple(views[name] for name in module._param_order)
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
 class NoiseModelBase(nn.Module):
@@ -290,4 +298,5 @@ class NoiseModelBase(nn.Module):
             return self._run_forward(x, t, y)[0]
         d = dict(self.named_parameters())
         params = [d[n] for n in self._param_order]
-        return _UNetFunction.apply(self, x, t, y, *params)
+        mode = MODE_TRAIN if self.training else MODE_EVAL_GRAD
+        return _UNetFunction.apply(self, mode, x, t, y, *params)
