@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the tiny-diffusion DDPM hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training step of the unconditional MNIST 28x28 UNet in fp32 on a
+per-GPU minibatch of 256 synthetic MNIST-shaped images (BASELINE.json configs[1];
+weak scaling for N > 1): t ~ U, q_sample, UNet forward (train-mode BatchNorm), MSE,
+backward of every parameter, gradient all-reduce (N > 1), Adam.  Rank 0 prints ONE
+JSON line.  `value` = images/s of the whole job; `roofline` = fp32-MFMA fraction of
+the 3x3 convolution kernels (>= 99.9 % of the FLOPs) timed live with HIP events;
+`cpu_baseline` = the CPU oracle (a port of the reference path, checked against the
+reference's own outputs) timed on this host; `sample` = wall-clock of the reference's
+1000-step reverse loop (graph-replayed) at n = 16 and n = 64.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 256
+FWD_FLOP_PER_IMAGE = 2_250_805_760          # SURVEY.md 8(d), measured on the reference
+TRAIN_FLOP_PER_IMAGE = 3 * FWD_FLOP_PER_IMAGE
+PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md (dense fp32 matrix)
+
+# (cin, cout, H) of the 13 conv/BN units, diffusion.py:32-95
+UNITS = [(64, 128, 28), (128, 128, 28), (128, 256, 14), (256, 256, 14), (256, 512, 7), (512, 512, 7),
+         (512, 512, 4), (1024, 256, 8), (256, 256, 8), (512, 128, 16), (128, 128, 16), (256, 64, 32),
+         (64, 64, 32)]
+
+
+def conv_roofline(B: int, reps: int = 5):
+    """Time every MFMA conv launch of one training step (13 x {fwd, dgrad, wgrad}) in
+    isolation with HIP events on the launch stream; FLOPs are algorithmic (2*M*9*cin*cout)."""
+    from tiny_diffusion_amd._lib import lib, check
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+    tot_flop = tot_ms = 0.0
+    n_launch = 0
+    for cin, cout, H in UNITS:
+        M = B * H * H
+        flop = 2.0 * M * 9 * cin * cout
+        x = torch.randn(M * cin, device=dev)
+        dy = torch.randn(M * cout, device=dev)
+        wf = torch.randn(cout * 9 * cin, device=dev) * 0.02
+        out = torch.empty(M * cout, device=dev)
+        gin = torch.empty(M * cin, device=dev)
+        tiles = lib.tdx_conv3x3_stat_tiles(B, H, H, cin, cout)
+        stats = torch.empty(tiles * 2 * cout, device=dev)
+        splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+        slabs = torch.empty(splits * cout * 9 * cin, device=dev)
+        bias = torch.zeros(cout, device=dev)
+
+        def fwd():
+            check(lib.tdx_conv3x3_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, cin,
+                                      cout, 4, None, None, None, None, stats.data_ptr(), st))
+
+        def dgrad():
+            check(lib.tdx_conv3x3_fwd(dy.data_ptr(), wf.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                      None, None, None, None, None, st))
+
+        def wgrad():
+            check(lib.tdx_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 0,
+                                        None, None, st))
+
+        for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            fn(); fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            rows.append({"cin": cin, "cout": cout, "hw": H, "role": name, "ms": round(ms, 4),
+                         "tflops": round(flop / ms / 1e9, 1)})
+            tot_flop += flop
+            tot_ms += ms
+            n_launch += 1
+    return rows, tot_flop, tot_ms, n_launch
+
+
+def cpu_baseline(batch: int = 64, steps: int = 6, threads: int = 16):
+    """The CPU oracle (port of diffusion.py:214-236: q_sample + fwd + MSE + bwd + Adam) on this
+    host's cores; bounded sample, reported beside the GPU number, never the target."""
+    from oracle import ref_cpu as R
+    from oracle.weights import make_state_dict
+
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    sd = make_state_dict(0, False)
+    sched = R.Schedule()
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.rand(batch, 1, 28, 28, generator=g) * 2 - 1
+    state = {}
+    params = {k: v.clone() for k, v in sd.items() if "running" not in k and "num_batches" not in k}
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        t = torch.randint(0, 1000, (batch,), generator=g)
+        noise = torch.randn(x0.shape, generator=g)
+        x_t = R.q_sample(sched, x0, t, noise)
+        full = dict(sd); full.update(params)
+        loss, _, grads, bufs = R.train_step_grads(full, x_t, t, noise)
+        R.adam_step(params, grads, state)
+        sd.update(bufs)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps          # first step is warm-up
+    return {"value": round(batch / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps at B={batch} (configs[0]) after 1 warm-up, oracle/ref_cpu.py"}
+
+
+def sample_latency(model, diffusion, n: int):
+    from tiny_diffusion_amd.diffusion import sample
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = sample(model, diffusion, "cuda", n_samples=n, use_graph=True, philox_seed=7)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu baseline / sampling legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
+    from tiny_diffusion_amd.train import TrainStep
+
+    torch.manual_seed(0)                      # identical init on every rank
+    model = NoiseModel().to(dev).train()
+    fp = ForwardProcess()
+    ts = TrainStep(model, fp, lr=1e-3, philox_seed=1234 + rank)
+    ts.broadcast_parameters(0)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    x0 = torch.rand(PER_GPU_BATCH, 1, 28, 28, device=dev, generator=g) * 2 - 1   # Normalize(0.5,0.5) range
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        ts.step(x0)
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(x0)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    loss_v = loss.item()
+    if not (loss_v == loss_v) or loss_v > 1e3:
+        raise SystemExit(f"training diverged in the benchmark: loss {loss_v}")
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * PER_GPU_BATCH * args.steps / dt
+        res = {
+            "metric": "train images/s (q_sample+fwd+MSE+bwd+allreduce+Adam), MNIST 28x28 UNet fp32; "
+                      "1000-step sample latency in `sample`",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "diffusion.py unconditional MNIST 28x28 UNet, fp32, train step, "
+                                   f"batch {PER_GPU_BATCH}/GPU (BASELINE.json configs[1])",
+                       "global_batch": world * PER_GPU_BATCH, "per_gpu_batch": PER_GPU_BATCH,
+                       "parallelism": f"dp{world}", "timesteps": 1000},
+            "images_per_s_per_gpu": round(value / world, 1),
+            "loss_after": round(loss_v, 5),
+            "train_tflops_per_gpu": round(value / world * TRAIN_FLOP_PER_IMAGE / 1e12, 2),
+        }
+        if not args.no_extras and world == 1:
+            rows, flop, ms, nl = conv_roofline(PER_GPU_BATCH)
+            ach = flop / ms / 1e9
+            res["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "conv3x3_igemm_kernel (fwd, dgrad) + conv3x3_wgrad_kernel",
+                "launches_per_step": nl, "conv_ms_per_step": round(ms, 3),
+                "algorithmic_gflop_per_step": round(flop / 1e9, 1),
+                "whole_step_frac": round(value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "per_launch": rows,
+            }
+            res["cpu_baseline"] = cpu_baseline()
+            model.eval()
+            res["sample"] = {"unit": "s per 1000-step chain (HIP-graph replay, in-kernel Philox noise)",
+                             "n16": round(sample_latency(model, fp, 16), 3),
+                             "n64": round(sample_latency(model, fp, 64), 3)}
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

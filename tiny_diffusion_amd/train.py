@@ -1,0 +1,170 @@
+"""The reference's training step (diffusion.py:214-236) as one fused pipeline on
+libtdx, with optional data-parallel gradient averaging over RCCL:
+
+    t ~ U{0..T-1};  x_t, eps = q_sample(x_0, t);  eps_hat = UNet(x_t, t[, y])
+    loss = mse(eps_hat, eps);  backward;  [all-reduce grads];  Adam
+
+No autograd graph is built: forward, loss gradient, the staged backward and the
+optimizer are libtdx launches on the current stream.  Parameters, gradients and
+Adam moments live in three flat fp32 buffers (the module's parameters are views
+into the first), so the optimizer is ONE kernel over 11.18 M elements and a
+gradient bucket is a contiguous slice.
+
+Data parallelism (one process per GPU, torch.distributed backend "nccl" = RCCL):
+the minibatch is sharded over ranks; after each backward stage the gradient
+slice that just became final is all-reduced asynchronously (RCCL runs it on its
+own stream, ordered after the stage's kernels) while the next stage computes;
+the averaged gradient is consumed by Adam after the last wait.  BatchNorm
+statistics stay rank-local (DistributedDataParallel semantics).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from ._lib import lib, check
+from .schedule import ForwardProcess
+from .unet import MODE_TRAIN, MODE_EVAL_GRAD, NoiseModelBase, backward_stage_params
+
+
+def merge_ranges(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def plan_buckets(offsets, cond: bool, bucket_floats: int):
+    """Group consecutive backward stages (unet.backward_stage_params) into buckets of at
+    least ``bucket_floats`` gradient elements.  Returns [(last_stage, [(lo, hi), ...])]:
+    after ``last_stage`` has run, those slices of the flat gradient are final."""
+    stages = backward_stage_params(cond)
+    buckets: List[Tuple[int, List[Tuple[int, int]]]] = []
+    cur: List[Tuple[int, int]] = []
+    size = 0
+    for s, names in enumerate(stages):
+        for n in names:
+            cur.append(offsets[n])
+            size += offsets[n][1] - offsets[n][0]
+        if size >= bucket_floats or s == len(stages) - 1:
+            buckets.append((s, merge_ranges(cur)))
+            cur, size = [], 0
+    return buckets
+
+
+class BucketedAllReduce:
+    """Sum-all-reduce of slices of one flat gradient buffer, launched bucket by bucket as
+    the backward produces them (async: the backend orders each collective after the work
+    already queued on the current stream and runs it on its own stream), waited for once
+    before the optimizer.  Works with any torch.distributed backend (RCCL on GPUs; gloo
+    in the CPU tests)."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None):
+        self.flat = flat_grad
+        self.buckets = buckets
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self._works = []
+
+    def launch(self, bucket_index: int):
+        if self.world == 1:
+            return
+        for lo, hi in self.buckets[bucket_index][1]:
+            self._works.append(torch.distributed.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
+
+    def finish(self) -> float:
+        """Wait for every launched collective; returns the scale (1/world) that turns the
+        summed gradient into the mean (folded into the Adam kernel)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return 1.0 / self.world
+
+
+class TrainStep:
+    def __init__(self, model: NoiseModelBase, diffusion: ForwardProcess, lr: float = 1e-3,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None):
+        self.model = model
+        self.diffusion = diffusion
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.pg = process_group
+        self.philox_seed = philox_seed
+        self._flatten()
+        self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats)
+        assert self.buckets[-1][0] == self.n_stages - 1
+        self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
+        self.world = self.reducer.world
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ setup
+    def _flatten(self):
+        m = self.model
+        named = dict(m.named_parameters())
+        order = m._param_order
+        dev = named[order[0]].device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainStep needs the model on a CUDA (ROCm) device")
+        self.device = dev
+        total = sum(named[n].numel() for n in order)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.offsets = {}
+        o = 0
+        for n in order:
+            p = named[n]
+            k = p.numel()
+            flat[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)   # parameters become views of the flat buffer
+            self.offsets[n] = (o, o + k)
+            o += k
+        self.flat_param = flat
+        self.flat_grad, self.grad_views = m._grad_buffers(dev)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.n_stages = lib.tdx_unet_backward_stages()
+
+    # ------------------------------------------------------------------- step
+    def step(self, x_0: torch.Tensor, y: Optional[torch.Tensor] = None,
+             t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimisation step on the local shard ``x_0`` (B,1,28,28); returns the
+        (device, not synchronised) loss tensor."""
+        m, fp = self.model, self.diffusion
+        B = x_0.shape[0]
+        dev = x_0.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if t is None:
+            t = torch.randint(0, fp.num_timesteps, (B,), device=dev)          # diffusion.py:220-222
+        if noise is None and self.philox_seed is not None:
+            x_t, noise = fp.q_sample_philox(x_0, t, self.philox_seed, self.step_count)
+        else:
+            x_t, noise = fp.q_sample(dev, x_0, t, noise=noise)                 # diffusion.py:225
+        mode = MODE_TRAIN if m.training else MODE_EVAL_GRAD
+        eps_hat, plan, _ = m._run_forward(x_t, t, y, mode=mode)               # diffusion.py:228
+        d_out = torch.empty_like(eps_hat)
+        check(lib.tdx_mse_loss(eps_hat.data_ptr(), noise.data_ptr(), self.loss.data_ptr(), d_out.data_ptr(),
+                               1.0, eps_hat.numel(), st), "tdx_mse_loss")      # diffusion.py:231
+        lo_stage = 0
+        for bi, (last_stage, _) in enumerate(self.buckets):                    # diffusion.py:235
+            m._run_backward(plan, d_out, self.grad_views, lo_stage, last_stage + 1)
+            lo_stage = last_stage + 1
+            self.reducer.launch(bi)          # overlaps with the next stages' kernels
+        gscale = self.reducer.finish()
+        self.step_count += 1
+        check(lib.tdx_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
+                                self.betas[1], self.eps, self.step_count, gscale, st),
+              "tdx_adam_step")                                                 # diffusion.py:236
+        return self.loss
+
+    def broadcast_parameters(self, src: int = 0):
+        """Identical replicas at start (parameters and BN buffers)."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.flat_param, src, group=self.pg)
+            for b in self.model.buffers():
+                torch.distributed.broadcast(b, src, group=self.pg)

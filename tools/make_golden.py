@@ -261,6 +261,11 @@ def main():
     with open(os.path.join(OUT, "weights.sha256"), "w") as f:
         f.write(f"uncond seed0 {state_dict_sha256(make_state_dict(0, False))}\n")
         f.write(f"cond seed0 {state_dict_sha256(make_state_dict(0, True))}\n")
+        # default initialisation of the reference under torch.manual_seed(0)
+        torch.manual_seed(0)
+        f.write(f"init uncond_seed0 {state_dict_sha256(unc.NoiseModel().state_dict())}\n")
+        torch.manual_seed(0)
+        f.write(f"init cond_seed0 {state_dict_sha256(con.NoiseModel().state_dict())}\n")
     schedule_fixture(unc)
     fwd_fixture(unc, False, "train", 64)
     fwd_fixture(unc, False, "eval", 64)
