@@ -149,8 +149,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run, even with 1 rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
@@ -165,7 +167,7 @@ def main():
     x0 = torch.rand(PER_GPU_BATCH, 1, 28, 28, device=dev, generator=g) * 2 - 1   # Normalize(0.5,0.5) range
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -219,7 +221,7 @@ def main():
                              "n16": round(sample_latency(model, fp, 16), 3),
                              "n64": round(sample_latency(model, fp, 64), 3)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

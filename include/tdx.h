@@ -233,6 +233,10 @@ int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, size_t* offs
 int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const* buffers,
                   tdx_stream_t stream);
 
+/* Tuning knobs for experiments (process-global): "conv_tile" 0 auto | 1 128x128 | 2 128x64 |
+ * 3 64x64; "wgrad_target" workgroups aimed at by the wgrad pixel split. */
+int tdx_tune_set(const char* key, int value);
+
 /* Peak probes used by bench.py for measured roofline denominators. */
 int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream);
 int tdx_probe_stream_copy(const float* src, float* dst, int64_t n, tdx_stream_t stream);

@@ -9,49 +9,49 @@
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
 
-// Merge per-tile (sum, M2-about-the-tile-mean) partials with Chan's parallel-variance
-// formula in double.  block = 256 threads = 32 channels x 8 slices of the tile list.
-struct Moments {
-  double n, mean, m2;
-};
-__device__ static inline void chan_merge(Moments& a, double nb, double meanb, double m2b) {
-  if (nb <= 0.0) return;
-  const double n = a.n + nb;
-  const double delta = meanb - a.mean;
-  a.m2 += m2b + delta * delta * (a.n * nb / n);
-  a.mean += delta * (nb / n);
-  a.n = n;
-}
-
+// Merge per-tile (sum S_t, M2_t about the tile mean) partials.  Chan's parallel-variance
+// formula summed over all tiles at once:
+//     M2 = sum_t M2_t + sum_t S_t^2 / n_t - S^2 / N ,   S = sum_t S_t
+// The last two terms cancel, but they are accumulated in double: with |mean|/std up to 1e4 that
+// still leaves 8 significant digits, while the fp32-sensitive part (deviations inside a tile)
+// was centred before it was ever summed.  block = 16 channels x 16 interleaved tile slices.
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t count, int C,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* __restrict__ rmean, float* __restrict__ rvar,
                    int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ save_mean, float* __restrict__ save_rstd, int training) {
-  __shared__ double red[3][8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[3][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   if (training) {
-    Moments m = {0.0, 0.0, 0.0};
-    if (c < C)
-      for (int t = sl; t < tiles; t += 8) {
-        const int64_t r0 = (int64_t)t * tile_rows;
-        const double nt = (double)(r0 + tile_rows <= count ? tile_rows : count - r0);
+    double S = 0.0, Q = 0.0, R = 0.0;
+    if (c < C) {
+      const double inv_full = 1.0 / (double)tile_rows;
+      const int64_t last_rows = count - (int64_t)(tiles - 1) * tile_rows;
+      const double inv_last = 1.0 / (double)last_rows;
+#pragma unroll 4
+      for (int t = sl; t < tiles; t += 16) {
         const double st = (double)stats[((size_t)t * 2 + 0) * C + c];
         const double qt = (double)stats[((size_t)t * 2 + 1) * C + c];
-        chan_merge(m, nt, st / nt, qt);
+        S += st;
+        Q += qt;
+        R += st * st * (t == tiles - 1 ? inv_last : inv_full);
       }
-    red[0][sl][cl] = m.n;
-    red[1][sl][cl] = m.mean;
-    red[2][sl][cl] = m.m2;
+    }
+    red[0][sl][cl] = S;
+    red[1][sl][cl] = Q;
+    red[2][sl][cl] = R;
     __syncthreads();
     if (sl == 0 && c < C) {
-      Moments a = {0.0, 0.0, 0.0};
-      for (int k = 0; k < 8; ++k) chan_merge(a, red[0][k][cl], red[1][k][cl], red[2][k][cl]);
+      S = 0.0; Q = 0.0; R = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; R += red[2][k][cl]; }
       const double n = (double)count;
-      const double mean = a.mean;
-      const double var = a.m2 / n;  // biased, used to normalise
+      const double mean = S / n;
+      double m2 = Q + (R - S * S / n);
+      if (m2 < 0.0) m2 = 0.0;
+      const double var = m2 / n;  // biased, used to normalise
       const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
       const float sc = gamma[c] * rstd;
       scale[c] = sc;
@@ -59,7 +59,7 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, in
       if (save_mean) save_mean[c] = (float)mean;
       if (save_rstd) save_rstd[c] = rstd;
       if (rmean) {
-        const double unbiased = n > 1.0 ? a.m2 / (n - 1.0) : var;
+        const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
         rmean[c] = (1.0f - BN_MOMENTUM) * rmean[c] + BN_MOMENTUM * (float)mean;
         rvar[c] = (1.0f - BN_MOMENTUM) * rvar[c] + BN_MOMENTUM * (float)unbiased;
       }
@@ -86,7 +86,7 @@ extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_r
   if (training && ((int64_t)tiles * tile_rows < count || (int64_t)(tiles - 1) * tile_rows >= count))
     return TDX_E_BADARG;
   if (!training && (!running_mean || !running_var)) return TDX_E_BADARG;
-  bn_finalize_kernel<<<cdiv(C, 32), 256, 0, to_stream(stream)>>>(
+  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, to_stream(stream)>>>(
       stats_partial, tiles, tile_rows, count, C, gamma, beta, running_mean, running_var,
       num_batches_tracked, scale, shift, save_mean, save_rstd, training);
   TDX_CHECK_LAUNCH();

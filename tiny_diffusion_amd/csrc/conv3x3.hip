@@ -18,6 +18,7 @@
 // 32-63 take k+4..k+7) and issues four MFMAs from it; A and B use the same
 // permutation of k, so the sum over k is unchanged.
 #include "common.h"
+#include <cstring>
 
 #define BK 32   // K-tile: 32 channels of one tap
 #define BKP 36  // padded LDS row (floats)
@@ -89,21 +90,29 @@ conv3x3_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
   const int nk = 9 * (a.Cin / BK);
-  float4 ra[AI], rb[BI];
+  f32x4 ra[AI], rb[BI];  // ext-vector staging registers: arrays of HIP float4 structs fall back to
+                          // scratch once a sched_barrier sits between their definition and use
   float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // Software pipeline without conditionals on the staging registers: iteration kt
-  // issues the global loads of tile kt+1 (clamped: the last iteration re-loads the
-  // last tile and stores it into the idle buffer, which nobody reads), runs the
-  // MFMAs of tile kt from LDS, then writes the staged registers.  kt = -1 is the
-  // prologue (loads tile 0, no MFMAs).
+  // Software pipeline: iteration kt ISSUES the global loads of tile kt+1 first (clamped: the
+  // last iteration re-loads the last tile and stores it into the idle buffer, which nobody
+  // reads), then runs the 64 MFMAs of tile kt from LDS, then masks/transforms the staged
+  // registers and writes them to the other LDS buffer.  kt = -1 is the prologue.
+  // The loads are unconditional (out-of-image rows read pixel 0 and are zeroed afterwards)
+  // and fenced with sched_barrier: left to itself hipcc sinks the weight-tile loads BELOW the
+  // MFMA block to save registers and then waits for them with nothing left to overlap.
   int cur = 1;
   for (int kt = -1; kt < nk; ++kt) {
+    unsigned okmask = 0;
     {
       const int kn = min(kt + 1, nk - 1);
       const int cblk = kn / 9, tap = kn - cblk * 9;
       const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
       const int c0 = cblk * BK + ld_c4;
+      const int koff = tap * a.Cin + cblk * BK;
+      const int doff = dh * a.W + dw;
+#pragma unroll
+      for (int j = 0; j < BI; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + koff);
       if (IN_BN) {
         sc4 = *reinterpret_cast<const float4*>(a.in_scale + c0);
         sh4 = *reinterpret_cast<const float4*>(a.in_shift + c0);
@@ -112,22 +121,12 @@ conv3x3_igemm_kernel(ConvArgs a) {
       for (int i = 0; i < AI; ++i) {
         const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          v = *reinterpret_cast<const float4*>(a.in + (size_t)(a_pix[i] + dh * a.W + dw) * a.Cin + c0);
-          if (IN_BN) {
-            v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
-            v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
-            v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
-          }
-        }
-        ra[i] = v;
+        okmask |= ok ? (1u << i) : 0u;
+        const int pix = ok ? a_pix[i] + doff : 0;
+        ra[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)pix * a.Cin + c0);
       }
-      const int koff = tap * a.Cin + cblk * BK;
-#pragma unroll
-      for (int j = 0; j < BI; ++j) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + koff);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt >= 0) {
       const float* Ab = As + cur * BM * BKP + (wm * WTM + l31) * BKP + half * 4;
       const float* Bb = Bs + cur * BN * BKP + (wn * WTN + l31) * BKP + half * 4;
@@ -150,15 +149,25 @@ conv3x3_igemm_kernel(ConvArgs a) {
                   __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     {
       float* Ab = As + (cur ^ 1) * BM * BKP;
       float* Bb = Bs + (cur ^ 1) * BN * BKP;
 #pragma unroll
-      for (int i = 0; i < AI; ++i)
-        *reinterpret_cast<float4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = ra[i];
+      for (int i = 0; i < AI; ++i) {
+        f32x4 v = ra[i];
+        if (IN_BN) {
+          v[0] = fmaxf(fmaf(v[0], sc4.x, sh4.x), 0.f);
+          v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
+          v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
+          v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
+        }
+        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = v;
+      }
 #pragma unroll
       for (int j = 0; j < BI; ++j)
-        *reinterpret_cast<float4*>(Bb + (ld_row + 32 * j) * BKP + ld_c4) = rb[j];
+        *reinterpret_cast<f32x4*>(Bb + (ld_row + 32 * j) * BKP + ld_c4) = rb[j];
     }
     __syncthreads();
     cur ^= 1;
@@ -253,8 +262,21 @@ struct TileCfg {
   int bm, bn;
 };
 
+// tuning knobs (tdx_tune_set): 0 = heuristic
+static int g_force_tile = 0;          // 1: 128x128, 2: 128x64, 3: 64x64
+static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
+
+extern "C" int tdx_tune_set(const char* key, int value) {
+  if (!key) return TDX_E_BADARG;
+  if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }
+  if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
+  return TDX_E_BADARG;
+}
+
 static TileCfg pick_tile(int64_t M, int cout) {
   const TileCfg cands[3] = {{128, 128}, {128, 64}, {64, 64}};
+  if (g_force_tile >= 1 && g_force_tile <= 3 && cout % cands[g_force_tile - 1].bn == 0)
+    return cands[g_force_tile - 1];
   for (int i = 0; i < 3; ++i) {
     if (cout % cands[i].bn) continue;
     int64_t tiles = ((M + cands[i].bm - 1) / cands[i].bm) * (cout / cands[i].bn);
@@ -394,39 +416,31 @@ conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
-  float4 ra[AI], rb[BI];
+  f32x4 ra[AI], rb[BI];
   const int nk = (p_hi - p_lo + 31) / 32;
   int cur = 1;
-  for (int kt = -1; kt < nk; ++kt) {  // same register-staged pipeline as the forward kernel
+  for (int kt = -1; kt < nk; ++kt) {  // same load-first register-staged pipeline as the forward kernel
+    unsigned okA = 0, okB = 0;
     {
       const int pbase = p_lo + min(kt + 1, nk - 1) * 32;
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const int p = pbase + a_r0 + AROWS * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < p_hi) v = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.Cout + co0 + a_c4);
-        ra[i] = v;
+        const bool ok = p < p_hi;
+        okA |= ok ? (1u << i) : 0u;
+        ra[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)(ok ? p : 0) * a.Cout + co0 + a_c4);
       }
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const int p = pbase + b_r0 + BROWS * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < p_hi) {
-          const int r = p % HW;
-          const int ih = r / a.W + dh, iw = r % a.W + dw;
-          if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
-            v = *reinterpret_cast<const float4*>(a.in + (size_t)(p + dh * a.W + dw) * a.Cin + ci0 + b_c4);
-            if (IN_BN) {
-              v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
-              v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
-              v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
-              v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
-            }
-          }
-        }
-        rb[i] = v;
+        const int r = p % HW;
+        const int ih = r / a.W + dh, iw = r % a.W + dw;
+        const bool ok = p < p_hi && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        okB |= ok ? (1u << i) : 0u;
+        rb[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(ok ? p + dh * a.W + dw : 0) * a.Cin + ci0 + b_c4);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (kt >= 0) {
       const float* Ab = As + cur * 32 * BM + half * BM + wm * WTM + TM * l31;
       const float* Bb = Bs + cur * 32 * BN + half * BN + wn * WTN + TN * l31;
@@ -452,15 +466,28 @@ conv3x3_wgrad_kernel(WgradArgs a) {
             acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im], bf[in], acc[im][in], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     {
       float* Ab = As + (cur ^ 1) * 32 * BM;
       float* Bb = Bs + (cur ^ 1) * 32 * BN;
 #pragma unroll
-      for (int i = 0; i < AI; ++i)
-        *reinterpret_cast<float4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = ra[i];
+      for (int i = 0; i < AI; ++i) {
+        f32x4 v = ra[i];
+        if (!((okA >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = v;
+      }
 #pragma unroll
-      for (int i = 0; i < BI; ++i)
-        *reinterpret_cast<float4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = rb[i];
+      for (int i = 0; i < BI; ++i) {
+        f32x4 v = rb[i];
+        if (IN_BN) {
+          v[0] = fmaxf(fmaf(v[0], sc4.x, sh4.x), 0.f);
+          v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
+          v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
+          v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
+        }
+        if (!((okB >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = v;
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -489,7 +516,7 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
   c.bm = (cout % 128 == 0) ? 128 : 64;
   c.bn = (cin % 128 == 0) ? 128 : 64;
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
-  int64_t s = (1024 + tiles - 1) / tiles;
+  int64_t s = (g_wgrad_target + tiles - 1) / tiles;
   int64_t smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;

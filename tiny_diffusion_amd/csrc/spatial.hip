@@ -335,19 +335,32 @@ int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t 
   return 0;
 }
 
-// out[i] = sum_b partial[b*stride + i], i < count, fixed order, double accumulation
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                       int nblk, int stride, int count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+// out[i] = sum_b partial[b*stride + i], i < count.  Fixed summation order (deterministic),
+// double accumulation; block = 32 columns x 8 interleaved row slices.
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
+                       int stride, int count) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * stride + i];
-  out[i] = (float)s;
+  if (i < count) {
+#pragma unroll 4
+    for (int b = sl; b < nblk; b += 8) s += (double)partial[(size_t)b * stride + i];
+  }
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    out[i] = (float)t;
+  }
 }
 
 int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
                         hipStream_t st) {
-  reduce_partials_kernel<<<cdiv(count, 128), 128, 0, st>>>(partial, out, nblk, stride, count);
+  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, nblk, stride, count);
   TDX_CHECK_LAUNCH();
   return 0;
 }

@@ -15,58 +15,77 @@ __device__ static inline float silu_grad_f(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
-// One block per sample.  Each wave computes dot products cooperatively (4 floats per lane
-// of a 256-long row, then a wave reduction) so weight rows are read as full 1 KiB lines.
+// Dot products are computed cooperatively by a wave (4 floats per lane of a 256-long row, then
+// a wave reduction) so weight rows are read as full 1 KiB lines; four rows are in flight per
+// wave at a time.  Two launches: the embedding (grid B x 4) and the three projections
+// (grid B x 14, 64 of the 896 outputs per block) - the serial depth is 4 row-groups per wave.
+__device__ static inline void wave_dot4(const float* __restrict__ w0, int row_stride, const float4 v,
+                                        int lane, float (&out)[4]) {
+  float4 a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const float4*>(w0 + (size_t)k * row_stride + lane * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = wave_sum(a[k].x * v.x + a[k].y * v.y + a[k].z * v.z + a[k].w * v.w);
+}
+
 __global__ void __launch_bounds__(256)
-time_embed_fwd_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ y,
-                      const float* __restrict__ w1, const float* __restrict__ b1,
-                      const float* __restrict__ w2, const float* __restrict__ b2,
-                      const float* __restrict__ cls, const float* __restrict__ pw1,
-                      const float* __restrict__ pb1, const float* __restrict__ pw2,
-                      const float* __restrict__ pb2, const float* __restrict__ pw3,
-                      const float* __restrict__ pb3, float* __restrict__ pre_out,
-                      float* __restrict__ emb_out, float* __restrict__ t1, float* __restrict__ t2,
-                      float* __restrict__ t3) {
+time_emb_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ y,
+                const float* __restrict__ w1, const float* __restrict__ b1,
+                const float* __restrict__ w2, const float* __restrict__ b2,
+                const float* __restrict__ cls, float* __restrict__ pre_out,
+                float* __restrict__ emb_out) {
   __shared__ __attribute__((aligned(16))) float h[TD];
-  __shared__ __attribute__((aligned(16))) float emb[TD];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float tf = (float)t[n];
   const float pre = fmaf(w1[tid], tf, b1[tid]);  // Linear(1, 256): weight (256,1)
-  if (pre_out) pre_out[(size_t)n * TD + tid] = pre;
+  if (pre_out && q == 0) pre_out[(size_t)n * TD + tid] = pre;
   h[tid] = silu_f(pre);
   __syncthreads();
   const float4 hv = *reinterpret_cast<const float4*>(h + lane * 4);
-  for (int i = wave; i < TD; i += 4) {
-    const float4 wv = *reinterpret_cast<const float4*>(w2 + (size_t)i * TD + lane * 4);
-    float s = wv.x * hv.x + wv.y * hv.y + wv.z * hv.z + wv.w * hv.w;
-    s = wave_sum(s);
-    if (lane == 0) {
-      float e = s + b2[i];
-      if (y) e += cls[(size_t)y[n] * TD + i];
-      emb[i] = e;
+  const int i0 = q * 64 + wave * 16;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = i0 + g * 4;
+    float d[4];
+    wave_dot4(w2 + (size_t)i * TD, TD, hv, lane, d);
+    if (lane < 4) {
+      float e = d[lane] + b2[i + lane];
+      if (y) e += cls[(size_t)y[n] * TD + i + lane];
+      emb_out[(size_t)n * TD + i + lane] = e;
     }
   }
-  __syncthreads();
-  if (emb_out) emb_out[(size_t)n * TD + tid] = emb[tid];
-  const float4 ev = *reinterpret_cast<const float4*>(emb + lane * 4);
-  for (int o = wave; o < 128 + 256 + 512; o += 4) {
-    const float* wrow; float bias; float* dst;
-    if (o < 128) { wrow = pw1 + (size_t)o * TD; bias = pb1[o]; dst = t1 + (size_t)n * 128 + o; }
-    else if (o < 384) { wrow = pw2 + (size_t)(o - 128) * TD; bias = pb2[o - 128]; dst = t2 + (size_t)n * 256 + (o - 128); }
-    else { wrow = pw3 + (size_t)(o - 384) * TD; bias = pb3[o - 384]; dst = t3 + (size_t)n * 512 + (o - 384); }
-    const float4 wv = *reinterpret_cast<const float4*>(wrow + lane * 4);
-    float s = wv.x * ev.x + wv.y * ev.y + wv.z * ev.z + wv.w * ev.w;
-    s = wave_sum(s);
-    if (lane == 0) *dst = s + bias;
+}
+
+__global__ void __launch_bounds__(256)
+time_proj_kernel(const float* __restrict__ emb, const float* __restrict__ pw1,
+                 const float* __restrict__ pb1, const float* __restrict__ pw2,
+                 const float* __restrict__ pb2, const float* __restrict__ pw3,
+                 const float* __restrict__ pb3, float* __restrict__ t1, float* __restrict__ t2,
+                 float* __restrict__ t3) {
+  const int n = blockIdx.x, q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 ev = *reinterpret_cast<const float4*>(emb + (size_t)n * TD + lane * 4);
+  // block q covers outputs [64q, 64q+64) of the concatenated (128 | 256 | 512) projections
+  const float* w; const float* b; float* dst; int o0, width;
+  if (q < 2) { w = pw1; b = pb1; dst = t1; o0 = q * 64; width = 128; }
+  else if (q < 6) { w = pw2; b = pb2; dst = t2; o0 = (q - 2) * 64; width = 256; }
+  else { w = pw3; b = pb3; dst = t3; o0 = (q - 6) * 64; width = 512; }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int o = o0 + wave * 16 + g * 4;
+    float d[4];
+    wave_dot4(w + (size_t)o * TD, TD, ev, lane, d);
+    if (lane < 4) dst[(size_t)n * width + o + lane] = d[lane] + b[o + lane];
   }
 }
 
 int tdx_time_embed_fwd(const int64_t* t, const int64_t* y, const float* const* P, float* pre,
                        float* emb, float* t1, float* t2, float* t3, int B, hipStream_t st) {
-  time_embed_fwd_kernel<<<B, 256, 0, st>>>(
-      t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W], P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB],
-      P[TDX_P_TP1_W], P[TDX_P_TP1_B], P[TDX_P_TP2_W], P[TDX_P_TP2_B], P[TDX_P_TP3_W],
-      P[TDX_P_TP3_B], pre, emb, t1, t2, t3);
+  time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
+                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb);
+  TDX_CHECK_LAUNCH();
+  time_proj_kernel<<<dim3(B, 14), 256, 0, st>>>(emb, P[TDX_P_TP1_W], P[TDX_P_TP1_B], P[TDX_P_TP2_W],
+                                                P[TDX_P_TP2_B], P[TDX_P_TP3_W], P[TDX_P_TP3_B], t1,
+                                                t2, t3);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -79,6 +98,7 @@ __global__ void lin_wgrad_kernel(const float* __restrict__ g, const float* __res
   if (idx >= O * J) return;
   const int o = idx / J, j = idx - o * J;
   float s = 0.f, sb = 0.f;
+#pragma unroll 8
   for (int n = 0; n < B; ++n) {
     const float gv = g[(size_t)n * O + o];
     s = fmaf(gv, x[(size_t)n * J + j], s);
@@ -95,24 +115,37 @@ __global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __res
   if (idx >= B * J) return;
   const int n = idx / J, j = idx - n * J;
   float s = accumulate ? gx[idx] : 0.f;
+#pragma unroll 8
   for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * O + o], w[(size_t)o * J + j], s);
   gx[idx] = s;
 }
 
 // g_pre = g_h * silu'(pre);  dW1[j] = sum_n g_pre[n][j] * t[n];  db1[j] = sum_n g_pre[n][j]
-__global__ void time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
-                                   const int64_t* __restrict__ t, float* __restrict__ dw1,
-                                   float* __restrict__ db1, int B) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= TD) return;
+// block = 32 columns j x 8 interleaved slices of n
+__global__ void __launch_bounds__(256)
+time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
+                   const int64_t* __restrict__ t, float* __restrict__ dw1, float* __restrict__ db1,
+                   int B) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
   float sw = 0.f, sb = 0.f;
-  for (int n = 0; n < B; ++n) {
+#pragma unroll 4
+  for (int n = sl; n < B; n += 8) {
     const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
     sw = fmaf(gp, (float)t[n], sw);
     sb += gp;
   }
-  dw1[j] = sw;
-  db1[j] = sb;
+  red[0][sl][cl] = sw;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0) {
+    sw = 0.f; sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sw += red[0][k][cl]; sb += red[1][k][cl]; }
+    dw1[j] = sw;
+    db1[j] = sb;
+  }
 }
 
 // h[n][j] = silu(pre[n][j])
@@ -161,7 +194,7 @@ int tdx_time_embed_bwd(const int64_t* t, const int64_t* y, const float* const* P
   TDX_CHECK_LAUNCH();
   lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0);
   TDX_CHECK_LAUNCH();
-  time_l1_bwd_kernel<<<1, 256, 0, st>>>(g_h, pre, t, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   TDX_CHECK_LAUNCH();
   return 0;
 }

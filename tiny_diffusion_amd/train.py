@@ -19,6 +19,7 @@ statistics stay rank-local (DistributedDataParallel semantics).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -70,9 +71,12 @@ class BucketedAllReduce:
         self.world = torch.distributed.get_world_size(process_group) if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self._works = []
+        # TDX_FORCE_ALLREDUCE=1 exercises the collective path on a single rank (testing)
+        self.force = (os.environ.get("TDX_FORCE_ALLREDUCE") == "1" and torch.distributed.is_available()
+                      and torch.distributed.is_initialized())
 
     def launch(self, bucket_index: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for lo, hi in self.buckets[bucket_index][1]:
             self._works.append(torch.distributed.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
