@@ -114,6 +114,17 @@ int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float*
                     const float* in_scale, const float* in_shift,
                     const float* out_scale, const float* out_shift,
                     float* stats_partial, tdx_stream_t stream);
+/* Same convolution for latency-bound (small batch) shapes: when the tile grid would leave
+ * most of the 256 CUs idle, K = 9*cin is split over more workgroups, partial sums go to
+ * `scratch` (tdx_conv3x3_splitk_scratch_floats; 0 = no split for this shape) and a second
+ * launch reduces them in a fixed order and applies bias / the BN+ReLU epilogue.
+ * TDX_CONV_OUT_STATS is not available on this path. */
+int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias, float* out,
+                           int B, int H, int W, int cin, int cout, int flags,
+                           const float* in_scale, const float* in_shift,
+                           const float* out_scale, const float* out_shift,
+                           float* scratch, size_t scratch_floats, tdx_stream_t stream);
+size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout);
 
@@ -234,7 +245,8 @@ int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const* buffers,
                   tdx_stream_t stream);
 
 /* Tuning knobs for experiments (process-global): "conv_tile" 0 auto | 1 128x128 | 2 128x64 |
- * 3 64x64; "wgrad_target" workgroups aimed at by the wgrad pixel split. */
+ * 3 64x64; "wgrad_target" workgroups aimed at by the wgrad pixel split; "conv_impl" 0 | 1
+ * (one / two register stages); "splitk" 0 | 1. */
 int tdx_tune_set(const char* key, int value);
 
 /* Peak probes used by bench.py for measured roofline denominators. */

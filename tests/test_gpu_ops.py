@@ -187,6 +187,38 @@ def test_conv3x3_fwd_fused_bn_relu(tdx, B, H, cin, cout):
     assert rel_err(nchw(out), ref) < 3e-6
 
 
+@pytest.mark.parametrize("B,H,cin,cout", [(16, 4, 512, 512), (16, 8, 1024, 256), (1, 28, 128, 128), (5, 7, 512, 512),
+                                          (2, 16, 512, 128), (64, 4, 512, 512)])
+def test_conv3x3_fwd_splitk_inference(tdx, B, H, cin, cout):
+    """latency-bound shapes: K split over workgroups + deterministic reduce with the fused
+    bias/BN/ReLU epilogue; must equal the unsplit kernel's result up to summation order."""
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=7)
+    g = torch.Generator().manual_seed(8)
+    osc, osh = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.3
+    ref = F.relu(F.conv2d(x, w, b, padding=1) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
+    wf, _ = _pack(tdx, w)
+    need = tdx.lib.tdx_conv3x3_splitk_scratch_floats(B, H, H, cin, cout)
+    assert need > 0, "shape was expected to take the split-K path"
+    scratch = torch.full((need,), float("nan"), device="cuda")
+    xin, bd, oscd, oshd = dev(nhwc(x)), dev(b), dev(osc), dev(osh)
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, H, H, cout), float("nan"), device="cuda")
+        tdx.check(tdx.lib.tdx_conv3x3_fwd_splitk(xin.data_ptr(), wf.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H,
+                                                 cin, cout, 2, None, None, oscd.data_ptr(), oshd.data_ptr(),
+                                                 scratch.data_ptr(), need, stream()))
+        outs.append(out)
+    assert rel_err(nchw(outs[0]), ref) < 3e-6
+    assert torch.equal(outs[0], outs[1])  # fixed reduction order: bitwise reproducible
+    # a scratch that is too small silently uses fewer splits (or none), same result
+    small = torch.empty(max(need // 3, 1), device="cuda")
+    out2 = torch.empty((B, H, H, cout), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd_splitk(xin.data_ptr(), wf.data_ptr(), bd.data_ptr(), out2.data_ptr(), B, H, H,
+                                             cin, cout, 2, None, None, oscd.data_ptr(), oshd.data_ptr(),
+                                             small.data_ptr(), small.numel(), stream()))
+    assert rel_err(nchw(out2), ref) < 3e-6
+
+
 @pytest.mark.parametrize("B,H,cin,cout", CONV_CASES)
 def test_conv3x3_dgrad_and_wgrad(tdx, B, H, cin, cout):
     x, w, b = _conv_inputs(B, H, cin, cout, seed=2)

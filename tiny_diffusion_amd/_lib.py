@@ -63,6 +63,9 @@ _SIGS = {
     "tdx_pack_conv3x3": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_conv3x3_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "tdx_conv3x3_fwd_splitk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, _ptr]),
+    "tdx_conv3x3_splitk_scratch_floats": (C.c_size_t, [C.c_int] * 5),
     "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_stat_tile_rows": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
@@ -114,6 +117,18 @@ def _bind():
 
 
 _bind()
+
+
+def _apply_env_tuning():
+    """TDX_TUNE="conv_impl=1,conv_tile=3": process-wide tuning knobs (tdx_tune_set)."""
+    spec = os.environ.get("TDX_TUNE", "")
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        key, _, val = item.partition("=")
+        if lib.tdx_tune_set(key.encode(), int(val)) != 0:
+            raise TdxError(f"unknown TDX_TUNE knob {key!r}")
+
+
+_apply_env_tuning()
 
 
 def check(code: int, what: str = "tdx"):

@@ -36,6 +36,7 @@ struct ConvArgs {
   const float* out_shift;
   float* stats;  // [tilesM][2][Cout]
   int B, H, W, Cin, Cout, M, tilesN;
+  int splits, kt_per_split;  // split-K (variant 2): blockIdx.y = split, raw partials to `out`
 };
 
 template <int BM, int BN, bool IN_BN, int EPI>
@@ -257,6 +258,281 @@ conv3x3_igemm_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 2 of the forward/dgrad kernel: two register stages.  While the MFMAs of tile k
+// run from LDS[k&1], the registers loaded during iteration k-1 (tile k+1) are written to
+// LDS[(k+1)&1] in four slices BETWEEN the four MFMA groups, and the global loads of tile
+// k+2 are issued into the other register stage.  A load therefore has a whole iteration
+// (~4000 cycles) to land and the LDS stores ride in the shadow of the 64-cycle MFMAs, so a
+// wave's instruction stream is MFMA-dense even with no co-resident partner wave.
+template <int BM, int BN, bool IN_BN, int EPI, bool SPLITK = false>
+__global__ void __launch_bounds__(256)
+conv3x3_igemm2_kernel(ConvArgs a) {
+  constexpr int WGM = 2, WGN = 2;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * BKP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W;
+
+  const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
+  int a_pix[AI], a_oh[AI], a_ow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int p = m0 + ld_row + 32 * i;
+    if (p < a.M) {
+      int r = p % HW;
+      a_pix[i] = p; a_oh[i] = r / a.W; a_ow[i] = r % a.W;
+    } else {
+      a_pix[i] = 0; a_oh[i] = -100000; a_ow[i] = 0;
+    }
+  }
+  const float* wrow[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j)
+    wrow[j] = a.w + (size_t)(n0 + ld_row + 32 * j) * (9 * a.Cin) + ld_c4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  // K-tiles [kt0, kt0 + nk) of the 9*Cin/32 are this workgroup's share (all of them unless
+  // split-K spreads a small problem over more workgroups)
+  const int nk_total = 9 * (a.Cin / BK);
+  const int kt0 = SPLITK ? (int)blockIdx.y * a.kt_per_split : 0;
+  const int nk = SPLITK ? min(a.kt_per_split, nk_total - kt0) : nk_total;
+
+  struct Stage {
+    f32x4 ra[AI];
+    f32x4 rb[BI];
+    f32x4 sc, sh;
+    unsigned ok;
+  };
+  Stage S0, S1;
+
+  auto load_tile = [&](int kt, Stage& S) {
+    const int kn = kt0 + min(kt, nk - 1);
+    const int cblk = kn / 9, tap = kn - cblk * 9;
+    const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
+    const int c0 = cblk * BK + ld_c4;
+    const int koff = tap * a.Cin + cblk * BK;
+    const int doff = dh * a.W + dw;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) S.rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + koff);
+    if (IN_BN) {
+      S.sc = *reinterpret_cast<const f32x4*>(a.in_scale + c0);
+      S.sh = *reinterpret_cast<const f32x4*>(a.in_shift + c0);
+    }
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
+      const bool v = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      ok |= v ? (1u << i) : 0u;
+      const int pix = v ? a_pix[i] + doff : 0;
+      S.ra[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)pix * a.Cin + c0);
+    }
+    S.ok = ok;
+  };
+  // slice q (0..3) of the stores of a stage: AI/4 A rows and BI/4 B rows (at least one each
+  // when AI, BI >= 4; smaller tiles put everything into the first slices)
+  auto store_slice = [&](const Stage& S, int buf, int q) {
+    float* Ab = As + buf * BM * BKP;
+    float* Bb = Bs + buf * BN * BKP;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if ((i * 4) / AI != q) continue;
+      f32x4 v = S.ra[i];
+      if (IN_BN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], S.sc[e], S.sh[e]), 0.f);
+      }
+      if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      if ((j * 4) / BI != q) continue;
+      *reinterpret_cast<f32x4*>(Bb + (ld_row + 32 * j) * BKP + ld_c4) = S.rb[j];
+    }
+  };
+  auto mfma_group = [&](int buf, int ks) {
+    const float* Ab = As + buf * BM * BKP + (wm * WTM + l31) * BKP + half * 4;
+    const float* Bb = Bs + buf * BN * BKP + (wn * WTN + l31) * BKP + half * 4;
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const f32x4*>(Ab + im * 32 * BKP + ks * 8);
+#pragma unroll
+    for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BKP + ks * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+  };
+  // one iteration: compute tile kt from LDS[cur]; Sst (tile kt+1) -> LDS[cur^1]; load tile kt+2 -> Sld
+  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
+    load_tile(kt + 2, Sld);
+    // keep the loads at the top of the iteration: hipcc would otherwise sink them to the end,
+    // a few hundred cycles before the next iteration's first store waits for them
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      mfma_group(cur, ks);
+      store_slice(Sst, cur ^ 1, ks);
+    }
+    __syncthreads();
+  };
+
+  // prologue: tile 0 -> LDS[0], tile 1 -> S1 registers
+  load_tile(0, S0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) store_slice(S0, 0, q);
+  load_tile(1, S1);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, 0, S1, S0);      // S1 holds tile kt+1; load tile kt+2 into S0
+    iteration(kt + 1, 1, S0, S1);  // S0 holds tile kt+2; load tile kt+3 into S1
+  }
+  if (kt < nk) iteration(kt, 0, S1, S0);  // odd tail
+
+  if (SPLITK) {
+    // raw partial sums; bias / BN / ReLU are applied by splitk_reduce_kernel
+    float* part = a.out + (size_t)blockIdx.y * a.M * a.Cout;
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = n0 + wn * WTN + in * 32 + l31;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (p < a.M) part[(size_t)p * a.Cout + col] = acc[im][in][r];
+        }
+    }
+    return;
+  }
+
+  // ---- epilogue (identical to variant 1)
+  float csum[TN];
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int col = n0 + wn * WTN + in * 32 + l31;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float osc = 1.f, osh = 0.f;
+    if (EPI == EPI_BNRELU) { osc = a.out_scale[col]; osh = a.out_shift[col]; }
+    float s = 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int p = m0 + row;
+        float v = acc[im][in][r] + bv;
+        if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
+        acc[im][in][r] = v;
+        if (p < a.M) {
+          a.out[(size_t)p * a.Cout + col] = v;
+          s += v;
+        }
+      }
+    }
+    csum[in] = s;
+  }
+  if (EPI == EPI_STATS) {
+    float* red = smem;
+    const int rows_valid = min(BM, a.M - m0);
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
+    }
+    __syncthreads();
+    float* tsum = red + WGM * BN;
+    for (int c = tid; c < BN; c += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      tsum[c] = v;
+      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)rows_valid;
+    float cm2[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m0 + row < a.M) {
+            const float dlt = acc[im][in][r] - mean;
+            q = fmaf(dlt, dlt, q);
+          }
+        }
+      cm2[in] = q + __shfl_xor(q, 32, 64);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
+    }
+  }
+}
+
+// out[p][c] = epi(bias[c] + sum_s partial[s][p][c]); fixed summation order (deterministic)
+template <bool BNRELU>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t n4,
+                                     int cout, const float* __restrict__ bias,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     float* __restrict__ out) {
+  const int c4n = cout / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < splits; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (BNRELU) {
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      acc.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f);
+      acc.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+      acc.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f);
+      acc.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ dispatch
 struct TileCfg {
   int bm, bn;
@@ -264,11 +540,15 @@ struct TileCfg {
 
 // tuning knobs (tdx_tune_set): 0 = heuristic
 static int g_force_tile = 0;          // 1: 128x128, 2: 128x64, 3: 64x64
+static int g_conv_impl = 1;           // 0: variant 1 (one register stage), 1: variant 2 (default)
+static int g_splitk = 1;              // 0: never split K; 1: split K when the grid would not fill the chip
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 
 extern "C" int tdx_tune_set(const char* key, int value) {
   if (!key) return TDX_E_BADARG;
   if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }
+  if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
+  if (!strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
   return TDX_E_BADARG;
 }
@@ -295,13 +575,14 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
                                                  : EPI_PLAIN;
 #define TDX_LAUNCH(INBN, EPI_)                                                              \
   do {                                                                                      \
-    auto kern = conv3x3_igemm_kernel<BM, BN, INBN, EPI_>;                                   \
-    static bool attr_set = false;                                                           \
-    if (lds > 65536 && !attr_set) {                                                         \
+    auto kern = g_conv_impl ? conv3x3_igemm2_kernel<BM, BN, INBN, EPI_>                     \
+                            : conv3x3_igemm_kernel<BM, BN, INBN, EPI_>;                     \
+    static bool attr_set[2] = {false, false};                                               \
+    if (lds > 65536 && !attr_set[g_conv_impl ? 1 : 0]) {                                    \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                   \
-      attr_set = true;                                                                      \
+      attr_set[g_conv_impl ? 1 : 0] = true;                                                 \
     }                                                                                       \
     kern<<<grid, 256, lds, st>>>(a);                                                        \
   } while (0)
@@ -319,6 +600,52 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
   return 0;
 }
 
+// Split-K plan for an underfilled grid (small batch inference): 64x64 tiles, S contiguous
+// K ranges of >= 6 K-tiles each, aiming at ~2 workgroups per CU.
+static int plan_splitk(int64_t M, int cin, int cout, int* kt_per_split, size_t cap_floats = (size_t)-1) {
+  const TileCfg c = pick_tile(M, cout);
+  const int64_t tiles = ((M + c.bm - 1) / c.bm) * (cout / c.bn);
+  const int nk = 9 * (cin / BK);
+  if (!g_splitk || g_conv_impl == 0 || c.bm != 64 || tiles >= 192) { *kt_per_split = nk; return 1; }
+  int s = (int)((512 + tiles - 1) / tiles);
+  if (s > nk / 6) s = nk / 6;
+  const size_t fit = cap_floats / ((size_t)M * cout);   // never ask for more scratch than there is
+  if ((size_t)s > fit) s = (int)fit;
+  if (s < 2) { *kt_per_split = nk; return 1; }
+  const int per = (nk + s - 1) / s;
+  *kt_per_split = per;
+  return (nk + per - 1) / per;
+}
+
+extern "C" size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin, int cout) {
+  int per;
+  const int64_t M = (int64_t)B * H * W;
+  const int s = plan_splitk(M, cin, cout, &per);
+  return s > 1 ? (size_t)s * M * cout : 0;
+}
+
+template <int EPI_>
+static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scratch, hipStream_t st) {
+  float* final_out = a.out;
+  a.out = scratch;
+  a.splits = splits;
+  a.kt_per_split = per;
+  const size_t lds = (size_t)2 * (64 + 64) * BKP * sizeof(float);
+  dim3 grid(cdiv(a.M, 64) * a.tilesN, splits);
+  if (in_bn) conv3x3_igemm2_kernel<64, 64, true, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
+  else conv3x3_igemm2_kernel<64, 64, false, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
+  TDX_CHECK_LAUNCH();
+  const int64_t n4 = (int64_t)a.M * a.Cout / 4;
+  int rg = (int)((n4 + 255) / 256);
+  if (rg > 2048) rg = 2048;
+  if (EPI_ == EPI_BNRELU)
+    splitk_reduce_kernel<true><<<rg, 256, 0, st>>>(scratch, splits, n4, a.Cout, a.bias, a.out_scale, a.out_shift, final_out);
+  else
+    splitk_reduce_kernel<false><<<rg, 256, 0, st>>>(scratch, splits, n4, a.Cout, a.bias, nullptr, nullptr, final_out);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout) {
   (void)cin;
   int64_t M = (int64_t)B * H * W;
@@ -330,11 +657,12 @@ extern "C" int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout
   return pick_tile((int64_t)B * H * W, cout).bm;
 }
 
-extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,
-                               int B, int H, int W, int cin, int cout, int flags,
-                               const float* in_scale, const float* in_shift,
-                               const float* out_scale, const float* out_shift,
-                               float* stats_partial, tdx_stream_t stream) {
+static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias, float* out,
+                            int B, int H, int W, int cin, int cout, int flags,
+                            const float* in_scale, const float* in_shift,
+                            const float* out_scale, const float* out_shift,
+                            float* stats_partial, float* splitk_scratch, size_t scratch_floats,
+                            tdx_stream_t stream) {
   if (!in || !wpk || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   if (cin % BK || cout % 64) return TDX_E_SHAPE;
   if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
@@ -350,10 +678,40 @@ extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* b
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   TileCfg c = pick_tile(M64, cout);
   a.tilesN = cout / c.bn;
+  a.splits = 1;
+  a.kt_per_split = 9 * (cin / BK);
   hipStream_t st = to_stream(stream);
+  if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
+    int per;
+    const int splits = plan_splitk(M64, cin, cout, &per, scratch_floats);
+    if (splits > 1) {
+      const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+      if (flags & TDX_CONV_OUT_BNRELU) return launch_splitk<EPI_BNRELU>(a, in_bn, splits, per, splitk_scratch, st);
+      return launch_splitk<EPI_PLAIN>(a, in_bn, splits, per, splitk_scratch, st);
+    }
+  }
   if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128>(a, flags, st);
   if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64>(a, flags, st);
   return launch_conv<64, 64>(a, flags, st);
+}
+
+extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* bias, float* out,
+                               int B, int H, int W, int cin, int cout, int flags,
+                               const float* in_scale, const float* in_shift,
+                               const float* out_scale, const float* out_shift,
+                               float* stats_partial, tdx_stream_t stream) {
+  return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, in_scale, in_shift, out_scale,
+                          out_shift, stats_partial, nullptr, 0, stream);
+}
+
+extern "C" int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias, float* out,
+                                      int B, int H, int W, int cin, int cout, int flags,
+                                      const float* in_scale, const float* in_shift,
+                                      const float* out_scale, const float* out_shift,
+                                      float* scratch, size_t scratch_floats, tdx_stream_t stream) {
+  if (!scratch) return TDX_E_BADARG;
+  return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, in_scale, in_shift, out_scale,
+                          out_shift, nullptr, scratch, scratch_floats, stream);
 }
 
 // ---------------------------------------------------------------------- wgrad

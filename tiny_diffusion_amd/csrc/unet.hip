@@ -93,6 +93,11 @@ struct tdx_unet {
   size_t iss_off[13];
   bool packed;
   int saved_batch, saved_mode;  // state of the last forward (for backward)
+  // backward runs the weight-gradient GEMMs on a second (low-priority) HIP stream so that
+  // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
+  // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
+  hipStream_t side;
+  hipEvent_t ev_dy[13], ev_w[13], ev_join;
 };
 
 extern "C" int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes) {
@@ -115,12 +120,28 @@ extern "C" int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes) {
   u->packed = false;
   u->saved_batch = 0;
   u->saved_mode = -1;
+  int lo = 0, hi = 0;
+  hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
+  e = hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, lo);
+  if (e != hipSuccess) { hipFree(u->wpack); hipFree(u->infer_ss); delete u; return (int)e; }
+  for (int i = 0; i < 13; ++i) {
+    hipEventCreateWithFlags(&u->ev_dy[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&u->ev_w[i], hipEventDisableTiming);
+  }
+  hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming);
   *out = u;
   return 0;
 }
 
 extern "C" int tdx_unet_destroy(tdx_unet* u) {
   if (!u) return TDX_E_BADARG;
+  hipStreamSynchronize(u->side);
+  for (int i = 0; i < 13; ++i) {
+    hipEventDestroy(u->ev_dy[i]);
+    hipEventDestroy(u->ev_w[i]);
+  }
+  hipEventDestroy(u->ev_join);
+  hipStreamDestroy(u->side);
   hipFree(u->wpack);
   hipFree(u->infer_ss);
   delete u;
@@ -247,8 +268,11 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     float* ss = ws + L.ss[i];
     if (infer) {
       const float* iss = u->infer_ss + u->iss_off[i];
-      return tdx_conv3x3_fwd(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU,
-                             nullptr, nullptr, iss, iss + d.cout, nullptr, stream);
+      // small-batch sampling is latency-bound: split K over more workgroups where the tile
+      // grid would not fill the chip; the (unused in INFER mode) gradient buffer is the scratch
+      return tdx_conv3x3_fwd_splitk(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU,
+                                    nullptr, nullptr, iss, iss + d.cout, ws + L.G1,
+                                    (size_t)B * 32 * 32 * 256 * 2, stream);
     }
     int flags = (d.in_bn ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
     RC(tdx_conv3x3_fwd(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, flags,
@@ -322,6 +346,17 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   // unit:            0   1   2   3   4   5   6   7   8   9   10  11  12
   float* g_of[13] = {G2, G1, G1, G2, G2, G1, G1, G1, G2, G2, G1, G1, G2};
 
+  tdx_stream_t side = reinterpret_cast<tdx_stream_t>(u->side);
+  int pending_w = -1;  // unit whose wgrad (side stream) still reads its dy buffer
+  // Every kernel on the main stream that OVERWRITES the buffer holding dy of `pending_w`
+  // must first wait for that unit's wgrad.
+  auto wait_wgrad = [&]() -> int {
+    if (pending_w >= 0) {
+      TDX_HIP(hipStreamWaitEvent(st, u->ev_w[pending_w], 0));
+      pending_w = -1;
+    }
+    return 0;
+  };
   auto unit_bwd = [&](int i, const float* in, float* g_in) -> int {
     // g_of[i] holds dL/d(activation of unit i); afterwards it holds dL/d(conv output)
     const UnitDef& d = UNITS[i];
@@ -332,18 +367,26 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                        ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
                        G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
                        stream));
-    // weight gradient (input is the previous unit's pre-BN tensor when in_bn)
+    // fork: weight gradient on the side stream (input is the previous unit's pre-BN tensor
+    // when in_bn).  The slab buffer is only ever touched by the side stream, in order.
+    TDX_HIP(hipEventRecord(u->ev_dy[i], st));
+    TDX_HIP(hipStreamWaitEvent(u->side, u->ev_dy[i], 0));
     const float* isc = d.in_bn ? ws + L.ss[i - 1] : nullptr;
     const float* ish = d.in_bn ? ws + L.ss[i - 1] + UNITS[i - 1].cout : nullptr;
     RC(tdx_conv3x3_wgrad(in, g, ws + L.slabs, B, d.hw, d.hw, d.cin, d.cout,
-                         d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish, stream));
+                         d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish, side));
     RC(tdx_conv3x3_wgrad_reduce(ws + L.slabs, G[TDX_P_UNIT0 + 4 * i],
                                 tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
-                                stream));
-    // input gradient: the forward kernel on the flipped pack, channels swapped
-    if (g_in)
+                                side));
+    TDX_HIP(hipEventRecord(u->ev_w[i], u->side));
+    // main: input gradient = the forward kernel on the flipped pack, channels swapped.
+    // It writes g_in (the OTHER ping-pong buffer, whose previous dy reader must be done).
+    if (g_in) {
+      RC(wait_wgrad());
       RC(tdx_conv3x3_fwd(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0,
                          nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+    }
+    pending_w = i;
     return 0;
   };
   auto ssc = [&](int i) { return ws + L.ss[i]; };
@@ -359,6 +402,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 1: RC(unit_bwd(12, ws + L.Y[11], G1)); break;  // g(U11) in G1
       case 2:
         RC(unit_bwd(11, ws + L.cat1, G2));  // g(cat1) in G2
+        RC(wait_wgrad());                   // G1 (dy11) is overwritten next
         RC(tdx_bilinear_ac_bwd(G2, G1, B, 16, 16, 32, 32, 128, 256, 0, stream));          // g(U10) in G1
         RC(tdx_bilinear_ac_bwd(G2, ws + L.GS1, B, 28, 28, 32, 32, 128, 256, 128, stream));  // g(e1+t1)
         RC(tdx_pixel_sum(ws + L.GS1, ws + L.gt1, B, 784, 128, st));
@@ -366,6 +410,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 3: RC(unit_bwd(10, ws + L.Y[9], G2)); break;  // g(U9) in G2
       case 4:
         RC(unit_bwd(9, ws + L.cat2, G1));  // g(cat2) in G1
+        RC(wait_wgrad());
         RC(tdx_bilinear_ac_bwd(G1, G2, B, 8, 8, 16, 16, 256, 512, 0, stream));            // g(U8) in G2
         RC(tdx_bilinear_ac_bwd(G1, ws + L.GS2, B, 14, 14, 16, 16, 256, 512, 256, stream));
         RC(tdx_pixel_sum(ws + L.GS2, ws + L.gt2, B, 196, 256, st));
@@ -373,22 +418,26 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 5: RC(unit_bwd(8, ws + L.Y[7], G1)); break;  // g(U7) in G1
       case 6:
         RC(unit_bwd(7, ws + L.cat3, G2));  // g(cat3) in G2
+        RC(wait_wgrad());
         RC(tdx_bilinear_ac_bwd(G2, G1, B, 4, 4, 8, 8, 512, 1024, 0, stream));             // g(U6) in G1
         RC(tdx_bilinear_ac_bwd(G2, ws + L.GS3, B, 7, 7, 8, 8, 512, 1024, 512, stream));
         RC(tdx_pixel_sum(ws + L.GS3, ws + L.gt3, B, 49, 512, st));
         break;
       case 7:
         RC(unit_bwd(6, ws + L.e3p, G2));  // g(e3p) in G2
+        RC(wait_wgrad());
         RC(tdx_maxpool2_ceil_bwd(ws + L.Y[5], ssc(5), ssh(5), G2, ws + L.GS3, G1, B, 7, 7, 512, stream));  // g(U5) in G1
         break;
       case 8: RC(unit_bwd(5, ws + L.Y[4], G2)); break;  // g(U4) in G2
       case 9:
         RC(unit_bwd(4, ws + L.e2p, G1));  // g(e2p) in G1
+        RC(wait_wgrad());
         RC(tdx_maxpool2_ceil_bwd(ws + L.Y[3], ssc(3), ssh(3), G1, ws + L.GS2, G2, B, 14, 14, 256, stream));  // g(U3) in G2
         break;
       case 10: RC(unit_bwd(3, ws + L.Y[2], G1)); break;  // g(U2) in G1
       case 11:
         RC(unit_bwd(2, ws + L.e1p, G2));  // g(e1p) in G2
+        RC(wait_wgrad());
         RC(tdx_maxpool2_ceil_bwd(ws + L.Y[1], ssc(1), ssh(1), G2, ws + L.GS1, G1, B, 28, 28, 128, stream));  // g(U1) in G1
         break;
       case 12: RC(unit_bwd(1, ws + L.Y[0], G2)); break;  // g(U0) in G2
@@ -402,5 +451,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
         break;
     }
   }
+  // join: everything the side stream did is ordered before whatever follows on `stream`
+  TDX_HIP(hipEventRecord(u->ev_join, u->side));
+  TDX_HIP(hipStreamWaitEvent(st, u->ev_join, 0));
   return 0;
 }

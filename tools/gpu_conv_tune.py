@@ -7,6 +7,14 @@ import torch
 import bench
 from tiny_diffusion_amd._lib import lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+for impl in (0, 1):
+    lib.tdx_tune_set(b"conv_impl", impl)
+    lib.tdx_tune_set(b"conv_tile", 0)
+    rows, flop, ms, nl = bench.conv_roofline(B, reps=8)
+    fd = [r for r in rows if r["role"] != "wgrad"]
+    print(f"conv_impl {impl}: fwd+dgrad {sum(r['ms'] for r in fd):.3f} ms | " + " ".join(f"{r['tflops']:.0f}" for r in fd))
+if len(sys.argv) > 2:
+    lib.tdx_tune_set(b"conv_impl", int(sys.argv[2]))
 res = {}
 for tile, name in ((0, "auto"), (1, "128x128"), (2, "128x64"), (3, "64x64")):
     lib.tdx_tune_set(b"conv_tile", tile)
