@@ -209,7 +209,7 @@ def main():
             res["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "conv3x3_igemm_kernel (fwd, dgrad) + conv3x3_wgrad_kernel",
+                "kernel": "conv3x3_igemm2_kernel (fwd, dgrad) + conv3x3_wgrad_kernel",
                 "launches_per_step": nl, "conv_ms_per_step": round(ms, 3),
                 "algorithmic_gflop_per_step": round(flop / 1e9, 1),
                 "whole_step_frac": round(value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
