@@ -19,6 +19,7 @@
 // permutation of k, so the sum over k is unchanged.
 #include "common.h"
 #include <cstring>
+#include <type_traits>
 
 #define BK 32   // K-tile: 32 channels of one tap
 #define BKP 36  // padded LDS row (floats)
@@ -37,6 +38,8 @@ struct ConvArgs {
   float* stats;  // [tilesM][2][Cout]
   int B, H, W, Cin, Cout, M, tilesN;
   int splits, kt_per_split;  // split-K (variant 2): blockIdx.y = split, raw partials to `out`
+  int dbg;                   // timing experiments only (tdx_tune_set "conv_dbg"): 1 no barrier,
+                             // 2 no LDS stores, 4 no global loads in the main loop -> WRONG results
 };
 
 template <int BM, int BN, bool IN_BN, int EPI>
@@ -265,7 +268,7 @@ conv3x3_igemm_kernel(ConvArgs a) {
 // k+2 are issued into the other register stage.  A load therefore has a whole iteration
 // (~4000 cycles) to land and the LDS stores ride in the shadow of the 64-cycle MFMAs, so a
 // wave's instruction stream is MFMA-dense even with no co-resident partner wave.
-template <int BM, int BN, bool IN_BN, int EPI, bool SPLITK = false>
+template <int BM, int BN, bool IN_BN, int EPI, bool SPLITK = false, bool SCHED = false>
 __global__ void __launch_bounds__(256)
 conv3x3_igemm2_kernel(ConvArgs a) {
   constexpr int WGM = 2, WGN = 2;
@@ -387,17 +390,42 @@ conv3x3_igemm2_kernel(ConvArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
   };
   // one iteration: compute tile kt from LDS[cur]; Sst (tile kt+1) -> LDS[cur^1]; load tile kt+2 -> Sld
-  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
-    load_tile(kt + 2, Sld);
-    // keep the loads at the top of the iteration: hipcc would otherwise sink them to the end,
-    // a few hundred cycles before the next iteration's first store waits for them
-    __builtin_amdgcn_sched_barrier(0);
+  auto iteration = [&](auto sid, int kt, int cur, const Stage& Sst, Stage& Sld) {
+    constexpr int SID = decltype(sid)::value;  // distinct sched-group id per unrolled copy
+    if (SCHED || !(a.dbg & 4)) load_tile(kt + 2, Sld);
+    if (!SCHED) {
+      // keep the loads at the top of the iteration: hipcc would otherwise sink them to the
+      // end, a few hundred cycles before the next iteration's first store waits for them
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 8; ++ks) {
       mfma_group(cur, ks);
-      store_slice(Sst, cur ^ 1, ks);
+      if (SCHED || !(a.dbg & 2)) store_slice(Sst, cur ^ 1, ks);
     }
-    __syncthreads();
+    if (SCHED) {
+      // Ask the scheduler for an even interleave: the address arithmetic, the 8 global loads,
+      // the 8 LDS stores and the 16 fragment reads of one K-tile are dealt out between the
+      // 64-cycle MFMAs (which leave the issue port free most of the time) instead of sitting
+      // in clumps during which the matrix pipe drains.
+      constexpr int NMF = TM * TN * 16;        // MFMAs per K-tile per wave
+      constexpr int NDR = (TM + TN) * 4;       // ds_read_b128
+      constexpr int NVM = AI + BI;             // global_load_dwordx4
+      constexpr int NDW = AI + BI;             // ds_write_b128
+      constexpr int NVA = 14 * AI + 4 * BI + (IN_BN ? 9 * AI : 0) + 12;  // VALU (estimate)
+      constexpr int VPM = (NVA + NMF - 1) / NMF;
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, SID);  // fragments of the first group
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, SID);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, SID);
+        if (((i + 1) * (NDR - TM - TN)) / NMF > (i * (NDR - TM - TN)) / NMF)
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, SID);
+        if (((i + 1) * NVM) / NMF > (i * NVM) / NMF) __builtin_amdgcn_sched_group_barrier(0x020, 1, SID);
+        if (((i + 1) * NDW) / NMF > (i * NDW) / NMF) __builtin_amdgcn_sched_group_barrier(0x200, 1, SID);
+      }
+    }
+    if (SCHED || !(a.dbg & 1)) __syncthreads();
   };
 
   // prologue: tile 0 -> LDS[0], tile 1 -> S1 registers
@@ -408,10 +436,10 @@ conv3x3_igemm2_kernel(ConvArgs a) {
   __syncthreads();
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
-    iteration(kt, 0, S1, S0);      // S1 holds tile kt+1; load tile kt+2 into S0
-    iteration(kt + 1, 1, S0, S1);  // S0 holds tile kt+2; load tile kt+3 into S1
+    iteration(std::integral_constant<int, 0>{}, kt, 0, S1, S0);      // S1 holds tile kt+1; load kt+2 -> S0
+    iteration(std::integral_constant<int, 1>{}, kt + 1, 1, S0, S1);  // S0 holds tile kt+2; load kt+3 -> S1
   }
-  if (kt < nk) iteration(kt, 0, S1, S0);  // odd tail
+  if (kt < nk) iteration(std::integral_constant<int, 2>{}, kt, 0, S1, S0);  // odd tail
 
   if (SPLITK) {
     // raw partial sums; bias / BN / ReLU are applied by splitk_reduce_kernel
@@ -540,15 +568,19 @@ struct TileCfg {
 
 // tuning knobs (tdx_tune_set): 0 = heuristic
 static int g_force_tile = 0;          // 1: 128x128, 2: 128x64, 3: 64x64
-static int g_conv_impl = 1;           // 0: variant 1 (one register stage), 1: variant 2 (default)
+static int g_conv_impl = 0;           // main-loop variant of the non-split launches: 0 one register stage
+                                      // (default: fastest end to end in in-process A/B), 1 two stages,
+                                      // 2 two stages + sched_group_barrier interleave
+static int g_conv_dbg = 0;
 static int g_splitk = 1;              // 0: never split K; 1: split K when the grid would not fill the chip
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 
 extern "C" int tdx_tune_set(const char* key, int value) {
   if (!key) return TDX_E_BADARG;
   if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }
-  if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
+  if (!strcmp(key, "conv_impl")) { g_conv_impl = value < 0 || value > 2 ? 0 : value; return 0; }
   if (!strcmp(key, "splitk")) { g_splitk = value; return 0; }
+  if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
   return TDX_E_BADARG;
 }
@@ -583,14 +615,15 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
                                                  : EPI_PLAIN;
 #define TDX_LAUNCH(INBN, EPI_)                                                              \
   do {                                                                                      \
-    auto kern = g_conv_impl ? conv3x3_igemm2_kernel<BM, BN, INBN, EPI_>                     \
-                            : conv3x3_igemm_kernel<BM, BN, INBN, EPI_>;                     \
-    static bool attr_set[2] = {false, false};                                               \
-    if (lds > 65536 && !attr_set[g_conv_impl ? 1 : 0]) {                                    \
+    auto kern = g_conv_impl == 2 ? conv3x3_igemm2_kernel<BM, BN, INBN, EPI_, false, true>   \
+                : g_conv_impl    ? conv3x3_igemm2_kernel<BM, BN, INBN, EPI_>                \
+                                 : conv3x3_igemm_kernel<BM, BN, INBN, EPI_>;                \
+    static bool attr_set[3] = {false, false, false};                                        \
+    if (lds > 65536 && !attr_set[g_conv_impl]) {                                            \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                   \
-      attr_set[g_conv_impl ? 1 : 0] = true;                                                 \
+      attr_set[g_conv_impl] = true;                                                         \
     }                                                                                       \
     kern<<<grid, 256, lds, st>>>(a);                                                        \
   } while (0)
@@ -617,7 +650,7 @@ static int plan_splitk(int64_t M, int cin, int cout, int* kt_per_split, size_t c
   const int64_t tiles = ((M + c.bm - 1) / c.bm) * (cout / c.bn);
   const int nk = 9 * (cin / BK);
   *kt_per_split = nk;
-  if (!g_splitk || g_conv_impl == 0 || c.bm != 64 || tiles >= 192) return 1;
+  if (!g_splitk || c.bm != 64 || tiles >= 192) return 1;
   int s = (int)((512 + tiles - 1) / tiles);
   if (s > nk / 6) s = nk / 6;
   const size_t fit = cap_floats / ((size_t)M * cout);  // never ask for more scratch than there is
@@ -691,6 +724,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   a.tilesN = cout / c.bn;
   a.splits = 1;
   a.kt_per_split = 9 * (cin / BK);
+  a.dbg = g_conv_dbg;
   hipStream_t st = to_stream(stream);
   if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
     int per;
@@ -737,7 +771,7 @@ struct WgradArgs {
   float* slabs;     // [S][Cout][9][Cin]
   const float* in_scale;
   const float* in_shift;
-  int B, H, W, Cin, Cout, M, tilesCi, chunk;
+  int B, H, W, Cin, Cout, M, tilesCi, tilesCo, groups, chunk;
 };
 
 template <int BM, int BN, bool IN_BN>
@@ -759,14 +793,22 @@ conv3x3_wgrad_kernel(WgradArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
 
-  int t = blockIdx.x;
-  const int tile_ci = t % a.tilesCi; t /= a.tilesCi;
-  const int tap = t % 9;
-  const int tile_co = t / 9;
+  // Workgroup id -> (group g = (pixel chunk, co tile, ci tile), tap).  The nine taps of a group
+  // read the SAME dy chunk and (shifted) input chunk; ids are laid out so that they differ by
+  // multiples of 8 inside a block of 72 consecutive ids: the dispatcher deals consecutive ids
+  // round-robin over the 8 XCDs, so the nine land on one XCD at about the same time and share
+  // its L2 instead of fetching the chunk nine times from HBM (speed only, never correctness).
+  const int L = blockIdx.x;
+  const int g = (L / 72) * 8 + (L % 8);
+  const int tap = (L % 72) / 8;
+  if (g >= a.groups) return;
+  const int tiles = a.tilesCo * a.tilesCi;
+  const int split = g / tiles, tl = g % tiles;
+  const int tile_co = tl / a.tilesCi, tile_ci = tl % a.tilesCi;
   const int co0 = tile_co * BM, ci0 = tile_ci * BN;
   const int dh = tap / 3 - 1, dw = tap % 3 - 1;
   const int HW = a.H * a.W;
-  const int p_lo = blockIdx.y * a.chunk;
+  const int p_lo = split * a.chunk;
   const int p_hi = min(p_lo + a.chunk, a.M);
 
   const int a_c4 = (tid % ACH) * 4, a_r0 = tid / ACH;
@@ -785,84 +827,114 @@ conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
-  f32x4 ra[AI], rb[BI];
   const int nk = (p_hi - p_lo + 31) / 32;
-  int cur = 1;
-  for (int kt = -1; kt < nk; ++kt) {  // same load-first register-staged pipeline as the forward kernel
+
+  // Two register stages, like conv3x3_igemm2_kernel: while the 64 MFMAs of pixel-tile k run
+  // from LDS[k&1], the registers holding tile k+1 are written to LDS[(k+1)&1] in four slices
+  // between the MFMA groups and the loads of tile k+2 are issued into the other stage.
+  struct Stage {
+    f32x4 ra[AI];
+    f32x4 rb[BI];
+    unsigned okA, okB;
+  };
+  Stage S0, S1;
+  auto load_tile = [&](int kt, Stage& S) {
+    const int pbase = p_lo + min(kt, nk - 1) * 32;
     unsigned okA = 0, okB = 0;
-    {
-      const int pbase = p_lo + min(kt + 1, nk - 1) * 32;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const int p = pbase + a_r0 + AROWS * i;
-        const bool ok = p < p_hi;
-        okA |= ok ? (1u << i) : 0u;
-        ra[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)(ok ? p : 0) * a.Cout + co0 + a_c4);
-      }
-#pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        const int p = pbase + b_r0 + BROWS * i;
-        const int r = p % HW;
-        const int ih = r / a.W + dh, iw = r % a.W + dw;
-        const bool ok = p < p_hi && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        okB |= ok ? (1u << i) : 0u;
-        rb[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(ok ? p + dh * a.W + dw : 0) * a.Cin + ci0 + b_c4);
-      }
+    for (int i = 0; i < AI; ++i) {
+      const int p = pbase + a_r0 + AROWS * i;
+      const bool ok = p < p_hi;
+      okA |= ok ? (1u << i) : 0u;
+      S.ra[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)(ok ? p : 0) * a.Cout + co0 + a_c4);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt >= 0) {
-      const float* Ab = As + cur * 32 * BM + half * BM + wm * WTM + TM * l31;
-      const float* Bb = Bs + cur * 32 * BN + half * BN + wn * WTN + TN * l31;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        float af[TM], bf[TN];
-        if (TM == 2) {
-          float2 v = *reinterpret_cast<const float2*>(Ab + ks * 2 * BM);
-          af[0] = v.x; af[TM - 1] = v.y;
-        } else {
-          af[0] = Ab[ks * 2 * BM];
-        }
-        if (TN == 2) {
-          float2 v = *reinterpret_cast<const float2*>(Bb + ks * 2 * BN);
-          bf[0] = v.x; bf[TN - 1] = v.y;
-        } else {
-          bf[0] = Bb[ks * 2 * BN];
-        }
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im], bf[in], acc[im][in], 0, 0, 0);
-      }
+    for (int i = 0; i < BI; ++i) {
+      const int p = pbase + b_r0 + BROWS * i;
+      const int r = p % HW;
+      const int ih = r / a.W + dh, iw = r % a.W + dw;
+      const bool ok = p < p_hi && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      okB |= ok ? (1u << i) : 0u;
+      S.rb[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(ok ? p + dh * a.W + dw : 0) * a.Cin + ci0 + b_c4);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      float* Ab = As + (cur ^ 1) * 32 * BM;
-      float* Bb = Bs + (cur ^ 1) * 32 * BN;
+    S.okA = okA;
+    S.okB = okB;
+  };
+  auto store_slice = [&](const Stage& S, int buf, int q) {
+    float* Ab = As + buf * 32 * BM;
+    float* Bb = Bs + buf * 32 * BN;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        f32x4 v = ra[i];
-        if (!((okA >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = v;
+    for (int i = 0; i < AI; ++i) {
+      if ((i * 4) / AI != q) continue;
+      f32x4 v = S.ra[i];
+      if (!((S.okA >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if ((i * 4) / BI != q) continue;
+      f32x4 v = S.rb[i];
+      if (IN_BN) {
+        v[0] = fmaxf(fmaf(v[0], sc4.x, sh4.x), 0.f);
+        v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
+        v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
+        v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
+      }
+      if (!((S.okB >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = v;
+    }
+  };
+  auto mfma_steps = [&](int buf, int ks0) {  // four of the sixteen 2-pixel k-steps
+    const float* Ab = As + buf * 32 * BM + half * BM + wm * WTM + TM * l31;
+    const float* Bb = Bs + buf * 32 * BN + half * BN + wn * WTN + TN * l31;
+#pragma unroll
+    for (int ks = ks0; ks < ks0 + 4; ++ks) {
+      float af[TM], bf[TN];
+      if (TM == 2) {
+        float2 v = *reinterpret_cast<const float2*>(Ab + ks * 2 * BM);
+        af[0] = v.x; af[TM - 1] = v.y;
+      } else {
+        af[0] = Ab[ks * 2 * BM];
+      }
+      if (TN == 2) {
+        float2 v = *reinterpret_cast<const float2*>(Bb + ks * 2 * BN);
+        bf[0] = v.x; bf[TN - 1] = v.y;
+      } else {
+        bf[0] = Bb[ks * 2 * BN];
       }
 #pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        f32x4 v = rb[i];
-        if (IN_BN) {
-          v[0] = fmaxf(fmaf(v[0], sc4.x, sh4.x), 0.f);
-          v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
-          v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
-          v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
-        }
-        if (!((okB >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = v;
-      }
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im], bf[in], acc[im][in], 0, 0, 0);
+    }
+  };
+  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
+    load_tile(kt + 2, Sld);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top (see conv3x3_igemm2_kernel)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mfma_steps(cur, q * 4);
+      store_slice(Sst, cur ^ 1, q);
     }
     __syncthreads();
-    cur ^= 1;
-  }
+  };
 
-  float* slab = a.slabs + (size_t)blockIdx.y * a.Cout * 9 * a.Cin;
+  if (nk > 0) {
+    load_tile(0, S0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_slice(S0, 0, q);
+    load_tile(1, S1);
+  }
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, 0, S1, S0);
+    iteration(kt + 1, 1, S0, S1);
+  }
+  if (kt < nk) iteration(kt, 0, S1, S0);
+
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll
   for (int im = 0; im < TM; ++im)
 #pragma unroll
@@ -904,7 +976,7 @@ extern "C" int tdx_conv3x3_wgrad_splits(int B, int H, int W, int cin, int cout) 
 template <int BM, int BN>
 static int launch_wgrad(const WgradArgs& a, int splits, bool in_bn, hipStream_t st) {
   const size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
-  dim3 grid((a.Cout / BM) * 9 * a.tilesCi, splits);
+  dim3 grid((unsigned)(((int64_t)a.groups + 7) / 8 * 72));
   if (in_bn) conv3x3_wgrad_kernel<BM, BN, true><<<grid, 256, lds, st>>>(a);
   else conv3x3_wgrad_kernel<BM, BN, false><<<grid, 256, lds, st>>>(a);
   TDX_CHECK_LAUNCH();
@@ -924,7 +996,8 @@ extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_sla
   WgradArgs a;
   a.in = in; a.dy = dy; a.slabs = dw_slabs; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
-  a.tilesCi = cin / c.bn; a.chunk = c.chunk;
+  a.tilesCi = cin / c.bn; a.tilesCo = cout / c.bm; a.chunk = c.chunk;
+  a.groups = a.tilesCi * a.tilesCo * c.splits;
   hipStream_t st = to_stream(stream);
   if (c.bm == 128 && c.bn == 128) return launch_wgrad<128, 128>(a, c.splits, in_bn, st);
   if (c.bm == 128 && c.bn == 64) return launch_wgrad<128, 64>(a, c.splits, in_bn, st);
