@@ -78,6 +78,13 @@ int tdx_p_sample_step_philox(float* x_out, const float* x, const float* eps,
                              const float* coef, const int32_t* t_idx, int64_t n,
                              uint64_t seed, tdx_stream_t stream);
 
+/* Caller side of the path: minibatch gather from a device-resident uint8
+ * dataset fused with ToTensor + Normalize((mean,),(std,)) of diffusion.py:202-204:
+ *   out[b] = ((u8[idx[b]] / 255) - mean) / std      (idx == NULL: rows 0..batch-1)
+ * Bit-exact with the reference's two transforms.  5 B/element. */
+int tdx_u8_gather_normalize(const uint8_t* data, const int64_t* idx, float* out, int batch,
+                            int per_sample, float mean, float stdv, tdx_stream_t stream);
+
 /* mean((a-b)^2) -> out[0] (F.mse_loss, diffusion.py:231) and its gradient
  * d_a = 2*(a-b)/n * gscale.  Either output may be NULL. */
 int tdx_mse_loss(const float* a, const float* b, float* loss_out, float* d_a,

@@ -395,3 +395,27 @@ def test_mse_and_adam(tdx):
         tdx.check(tdx.lib.tdx_adam_step(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), 10000,
                                         1e-3, 0.9, 0.999, 1e-8, step, 1.0, stream()))
     assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6
+
+
+def test_u8_gather_normalize_bit_exact(tdx):
+    """ToTensor + Normalize((0.5,),(0.5,)) (diffusion.py:202-204) fused with the gather."""
+    from tiny_diffusion_amd.data import DeviceImageDataset
+
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randint(0, 256, (500, 28, 28), generator=g, dtype=torch.uint8)
+    imgs[0].fill_(0); imgs[1].fill_(255)
+    ds = DeviceImageDataset(imgs)
+    idx = torch.randint(0, 500, (77,), generator=g)
+    got = ds.batch(idx.cuda())
+    ref = imgs[idx].float().div(255).sub(0.5).div(0.5).unsqueeze(1)   # the reference's transforms
+    assert got.shape == (77, 1, 28, 28) and torch.equal(got.cpu(), ref)
+    allb = ds.batch()
+    assert torch.equal(allb.cpu(), imgs.float().div(255).sub(0.5).div(0.5).unsqueeze(1))
+    assert allb.min().item() == -1.0 and allb.max().item() == 1.0
+    seen = torch.cat([b for b in ds.epoch(128, shuffle=True)])
+    assert seen.shape[0] == 500
+    # a shuffled epoch visits every image exactly once: compare per-image checksums as multisets
+    key = lambda t: torch.sort((t.double().view(t.shape[0], -1) * torch.arange(1, 785, device=t.device)).sum(1)).values
+    assert torch.equal(key(seen), key(allb))
+    with pytest.raises(IndexError):
+        ds.batch(torch.tensor([500]).cuda())

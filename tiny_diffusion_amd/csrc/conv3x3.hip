@@ -63,27 +63,39 @@ conv3x3_igemm_kernel(ConvArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
-  // ---- per-thread A rows: pixel coordinates (fixed across the K loop)
+  // ---- loaders.  On gfx950 the fp32 "matrix" instruction runs at the vector-ALU rate and every
+  // VALU instruction in the loop competes with it, so the per-tile address work is kept off the
+  // vector unit: tiles are fetched with BUFFER loads whose address is
+  //     descriptor base (SGPRs) + per-thread row offset (one VGPR, fixed) + per-tile offset (one SGPR)
+  // and zero padding is the hardware range check: a row outside the image gets an offset beyond
+  // num_records and the load returns 0.  Per row and K-tile that leaves one bit test + select.
   const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
-  int a_pix[AI], a_oh[AI], a_ow[AI];
+  // the descriptor starts (W+1) pixels BEFORE the tensor so that every tap's shift is >= 0
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0,
+                                                        a.Cout * 9 * a.Cin * 4, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off[AI], a_taps[AI];  // byte offset of (pixel, chunk); bit t set <=> tap t is inside the image
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int p = m0 + ld_row + 32 * i;
+    const int p = m0 + ld_row + 32 * i;
+    unsigned taps = 0;
     if (p < a.M) {
-      int r = p % HW;
-      a_pix[i] = p;
-      a_oh[i] = r / a.W;
-      a_ow[i] = r % a.W;
-    } else {
-      a_pix[i] = 0;
-      a_oh[i] = -100000;  // fails every bounds test
-      a_ow[i] = 0;
-    }
-  }
-  const float* wrow[BI];
+      const int r = p % HW, oh = r / a.W, ow = r % a.W;
 #pragma unroll
-  for (int j = 0; j < BI; ++j)
-    wrow[j] = a.w + (size_t)(n0 + ld_row + 32 * j) * (9 * a.Cin) + ld_c4;
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) taps |= 1u << t;
+      }
+    }
+    a_taps[i] = taps;
+    a_off[i] = (unsigned)(p * a.Cin + ld_c4) * 4u;
+  }
+  unsigned w_off[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) w_off[j] = (unsigned)((n0 + ld_row + 32 * j) * 9 * a.Cin + ld_c4) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -98,36 +110,34 @@ conv3x3_igemm_kernel(ConvArgs a) {
                           // scratch once a sched_barrier sits between their definition and use
   float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // Software pipeline: iteration kt ISSUES the global loads of tile kt+1 first (clamped: the
-  // last iteration re-loads the last tile and stores it into the idle buffer, which nobody
-  // reads), then runs the 64 MFMAs of tile kt from LDS, then masks/transforms the staged
-  // registers and writes them to the other LDS buffer.  kt = -1 is the prologue.
-  // The loads are unconditional (out-of-image rows read pixel 0 and are zeroed afterwards)
-  // and fenced with sched_barrier: left to itself hipcc sinks the weight-tile loads BELOW the
-  // MFMA block to save registers and then waits for them with nothing left to overlap.
+  // Software pipeline: iteration kt ISSUES the loads of tile kt+1 first (clamped: the last
+  // iteration re-loads the last tile and stores it into the idle buffer, which nobody reads),
+  // then runs the 64 MFMAs of tile kt from LDS, then writes the staged registers to the other
+  // LDS buffer.  kt = -1 is the prologue.  The loads are fenced with sched_barrier: left to
+  // itself hipcc sinks them BELOW the MFMA block and then waits with nothing left to overlap.
   int cur = 1;
   for (int kt = -1; kt < nk; ++kt) {
     unsigned okmask = 0;
     {
       const int kn = min(kt + 1, nk - 1);
       const int cblk = kn / 9, tap = kn - cblk * 9;
-      const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
       const int c0 = cblk * BK + ld_c4;
-      const int koff = tap * a.Cin + cblk * BK;
-      const int doff = dh * a.W + dw;
+      // tap shift relative to the descriptor base: ((kh)*W + kw)*Cin, kh,kw in 0..2
+      const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * BK) * 4u;
+      const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * BK) * 4u;
 #pragma unroll
-      for (int j = 0; j < BI; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + koff);
+      for (int j = 0; j < BI; ++j)
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
       if (IN_BN) {
         sc4 = *reinterpret_cast<const float4*>(a.in_scale + c0);
         sh4 = *reinterpret_cast<const float4*>(a.in_shift + c0);
       }
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
-        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        okmask |= ok ? (1u << i) : 0u;
-        const int pix = ok ? a_pix[i] + doff : 0;
-        ra[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)pix * a.Cin + c0);
+        const bool ok = (a_taps[i] >> tap) & 1u;
+        if (IN_BN) okmask |= ok ? (1u << i) : 0u;
+        ra[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? a_off[i] : OOB, soff_in, 0));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -161,12 +171,13 @@ conv3x3_igemm_kernel(ConvArgs a) {
       for (int i = 0; i < AI; ++i) {
         f32x4 v = ra[i];
         if (IN_BN) {
+          // padding must stay 0 AFTER the transform (relu(shift) != 0): only here is the mask needed
           v[0] = fmaxf(fmaf(v[0], sc4.x, sh4.x), 0.f);
           v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
           v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
           v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
+          if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = v;
       }
 #pragma unroll
@@ -772,6 +783,7 @@ struct WgradArgs {
   const float* in_scale;
   const float* in_shift;
   int B, H, W, Cin, Cout, M, tilesCi, tilesCo, groups, chunk;
+  int adv_q, adv_s;  // 32 pixels = adv_q rows + adv_s columns of a W-wide image
 };
 
 template <int BM, int BN, bool IN_BN>
@@ -838,8 +850,22 @@ conv3x3_wgrad_kernel(WgradArgs a) {
     unsigned okA, okB;
   };
   Stage S0, S1;
+  // (oh, ow) of each B row this thread stages, advanced by 32 pixels per K-tile with adds and
+  // conditional subtracts: load_tile is called for tiles 0, 1, 2, ... in order, and on the fp32
+  // "matrix" path every VALU instruction competes with the MFMAs for the same SIMD, so the
+  // two integer divisions per row and tile that used to sit here cost ~20 % of the kernel.
+  int b_oh[BI], b_ow[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = (p_lo + b_r0 + BROWS * i) % HW;
+    b_oh[i] = r / a.W;
+    b_ow[i] = r % a.W;
+  }
+  int tiles_issued = 0;
   auto load_tile = [&](int kt, Stage& S) {
     const int pbase = p_lo + min(kt, nk - 1) * 32;
+    const bool advance = kt > 0 && kt < nk && kt == tiles_issued;  // clamped tail calls re-load the last tile
+    if (kt == tiles_issued) ++tiles_issued;
     unsigned okA = 0, okB = 0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -851,8 +877,15 @@ conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int p = pbase + b_r0 + BROWS * i;
-      const int r = p % HW;
-      const int ih = r / a.W + dh, iw = r % a.W + dw;
+      if (advance) {
+        int ow = b_ow[i] + a.adv_s, oh = b_oh[i] + a.adv_q;  // 32 = adv_q * W + adv_s
+        if (ow >= a.W) { ow -= a.W; oh += 1; }
+        if (oh >= 2 * a.H) oh -= 2 * a.H;
+        if (oh >= a.H) oh -= a.H;
+        b_ow[i] = ow;
+        b_oh[i] = oh;
+      }
+      const int ih = b_oh[i] + dh, iw = b_ow[i] + dw;
       const bool ok = p < p_hi && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
       okB |= ok ? (1u << i) : 0u;
       S.rb[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(ok ? p + dh * a.W + dw : 0) * a.Cin + ci0 + b_c4);
@@ -998,6 +1031,8 @@ extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_sla
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   a.tilesCi = cin / c.bn; a.tilesCo = cout / c.bm; a.chunk = c.chunk;
   a.groups = a.tilesCi * a.tilesCo * c.splits;
+  a.adv_q = 32 / W; a.adv_s = 32 % W;
+  if (H < 4 && 32 / W + 1 >= 2 * H) return TDX_E_SHAPE;  // two conditional subtracts must suffice
   hipStream_t st = to_stream(stream);
   if (c.bm == 128 && c.bn == 128) return launch_wgrad<128, 128>(a, c.splits, in_bn, st);
   if (c.bm == 128 && c.bn == 64) return launch_wgrad<128, 64>(a, c.splits, in_bn, st);
