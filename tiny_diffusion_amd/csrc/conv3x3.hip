@@ -847,13 +847,31 @@ conv3x3_wgrad_kernel(WgradArgs a) {
   struct Stage {
     f32x4 ra[AI];
     f32x4 rb[BI];
-    unsigned okA, okB;
+    unsigned okB;
   };
   Stage S0, S1;
+  // Buffer loads (see conv3x3_igemm_kernel): descriptor base in SGPRs + fixed per-thread row
+  // offset + per-tile scalar offset.  The dy descriptor ENDS at this workgroup's last pixel, so
+  // the ragged end of the pixel range is zero-filled by the hardware range check with no
+  // instruction at all; the input descriptor starts (W+1) pixels before the tensor so that the
+  // tap shift is a non-negative scalar, and a row whose tap falls outside the image gets an
+  // out-of-range offset.  (A dy row of zeros also cancels whatever the matching input row holds.)
+  constexpr unsigned OOB = 0x80000000u;
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0,
+                                                         (int)((int64_t)p_hi * a.Cout * 4), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  unsigned a_off[AI], b_off[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) a_off[i] = (unsigned)((a_r0 + AROWS * i) * a.Cout + co0 + a_c4) * 4u;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) b_off[i] = (unsigned)((b_r0 + BROWS * i) * a.Cin + ci0 + b_c4) * 4u;
+  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * 4u;
   // (oh, ow) of each B row this thread stages, advanced by 32 pixels per K-tile with adds and
-  // conditional subtracts: load_tile is called for tiles 0, 1, 2, ... in order, and on the fp32
-  // "matrix" path every VALU instruction competes with the MFMAs for the same SIMD, so the
-  // two integer divisions per row and tile that used to sit here cost ~20 % of the kernel.
+  // conditional subtracts (load_tile is called for tiles 0, 1, 2, ... in order): on the fp32
+  // "matrix" path every VALU instruction competes with the MFMAs for the same SIMD, and two
+  // integer divisions per row and tile used to cost ~20 % of the kernel.
   int b_oh[BI], b_ow[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
@@ -866,17 +884,14 @@ conv3x3_wgrad_kernel(WgradArgs a) {
     const int pbase = p_lo + min(kt, nk - 1) * 32;
     const bool advance = kt > 0 && kt < nk && kt == tiles_issued;  // clamped tail calls re-load the last tile
     if (kt == tiles_issued) ++tiles_issued;
-    unsigned okA = 0, okB = 0;
+    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 4u;
+    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 4u + tap_shift;
+    unsigned okB = 0;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int p = pbase + a_r0 + AROWS * i;
-      const bool ok = p < p_hi;
-      okA |= ok ? (1u << i) : 0u;
-      S.ra[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)(ok ? p : 0) * a.Cout + co0 + a_c4);
-    }
+    for (int i = 0; i < AI; ++i)
+      S.ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, a_off[i], soff_a, 0));
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int p = pbase + b_r0 + BROWS * i;
       if (advance) {
         int ow = b_ow[i] + a.adv_s, oh = b_oh[i] + a.adv_q;  // 32 = adv_q * W + adv_s
         if (ow >= a.W) { ow -= a.W; oh += 1; }
@@ -886,11 +901,11 @@ conv3x3_wgrad_kernel(WgradArgs a) {
         b_oh[i] = oh;
       }
       const int ih = b_oh[i] + dh, iw = b_ow[i] + dw;
-      const bool ok = p < p_hi && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      okB |= ok ? (1u << i) : 0u;
-      S.rb[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)(ok ? p + dh * a.W + dw : 0) * a.Cin + ci0 + b_c4);
+      const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      if (IN_BN) okB |= ok ? (1u << i) : 0u;
+      S.rb[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? b_off[i] : OOB, soff_b, 0));
     }
-    S.okA = okA;
     S.okB = okB;
   };
   auto store_slice = [&](const Stage& S, int buf, int q) {
@@ -899,9 +914,7 @@ conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       if ((i * 4) / AI != q) continue;
-      f32x4 v = S.ra[i];
-      if (!((S.okA >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = v;
+      *reinterpret_cast<f32x4*>(Ab + (a_r0 + AROWS * i) * BM + a_c4) = S.ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -912,8 +925,8 @@ conv3x3_wgrad_kernel(WgradArgs a) {
         v[1] = fmaxf(fmaf(v[1], sc4.y, sh4.y), 0.f);
         v[2] = fmaxf(fmaf(v[2], sc4.z, sh4.z), 0.f);
         v[3] = fmaxf(fmaf(v[3], sc4.w, sh4.w), 0.f);
+        if (!((S.okB >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // padding stays 0 after the transform
       }
-      if (!((S.okB >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(Bb + (b_r0 + BROWS * i) * BN + b_c4) = v;
     }
   };
