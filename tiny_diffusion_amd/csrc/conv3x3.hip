@@ -42,6 +42,114 @@ struct ConvArgs {
                              // 2 no LDS stores, 4 no global loads in the main loop -> WRONG results
 };
 
+// ---------------------------------------------------------------------------
+// Shared epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+//   SPLITK      raw partial sums to a.out + split*M*Cout (bias/BN applied by splitk_reduce_kernel)
+//   EPI_PLAIN   + bias
+//   EPI_BNRELU  relu((acc + bias) * scale + shift)                       (inference)
+//   EPI_STATS   + bias, and per-tile per-channel (sum, M2 about the TILE mean) from the accumulators
+//               still in registers (two reductions); centred partials are merged with Chan's
+//               formula in bn_finalize, so the variance never sees E[y^2]-E[y]^2 cancellation.
+template <int BM, int BN, int EPI, bool SPLITK>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / 64][BN / 64],
+                                              float* smem, int tile_m, int m0, int n0, int wm, int wn,
+                                              int l31, int half, int tid) {
+  constexpr int WGM = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = BM / 64, TN = BN / 64;
+  if (SPLITK) {
+    float* part = a.out + (size_t)blockIdx.y * a.M * a.Cout;
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = n0 + wn * WTN + in * 32 + l31;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (p < a.M) part[(size_t)p * a.Cout + col] = acc[im][in][r];
+        }
+    }
+    return;
+  }
+  float csum[TN];
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int col = n0 + wn * WTN + in * 32 + l31;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+    float osc = 1.f, osh = 0.f;
+    if (EPI == EPI_BNRELU) {
+      osc = a.out_scale[col];
+      osh = a.out_shift[col];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int p = m0 + row;
+        float v = acc[im][in][r] + bv;
+        if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
+        acc[im][in][r] = v;
+        if (p < a.M) {
+          a.out[(size_t)p * a.Cout + col] = v;
+          s += v;
+        }
+      }
+    }
+    csum[in] = s;
+  }
+  if (EPI == EPI_STATS) {
+    float* red = smem;  // [WGM][BN] + [BN] means, re-uses the tile buffers (K loop is over)
+    const int rows_valid = min(BM, a.M - m0);
+    __syncthreads();    // every wave is done with the tile buffers
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
+    }
+    __syncthreads();
+    float* tsum = red + WGM * BN;  // [BN] tile column sums
+    for (int c = tid; c < BN; c += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      tsum[c] = v;
+      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)rows_valid;
+    float cm2[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m0 + row < a.M) {
+            const float dlt = acc[im][in][r] - mean;
+            q = fmaf(dlt, dlt, q);
+          }
+        }
+      cm2[in] = q + __shfl_xor(q, 32, 64);
+    }
+    __syncthreads();  // everyone has read tsum/red
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
+    }
+  }
+}
+
 template <int BM, int BN, bool IN_BN, int EPI>
 __global__ void __launch_bounds__(256)
 conv3x3_igemm_kernel(ConvArgs a) {
@@ -188,88 +296,7 @@ conv3x3_igemm_kernel(ConvArgs a) {
     cur ^= 1;
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
-  //      row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  float csum[TN];
-#pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int col = n0 + wn * WTN + in * 32 + l31;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-    float osc = 1.f, osh = 0.f;
-    if (EPI == EPI_BNRELU) {
-      osc = a.out_scale[col];
-      osh = a.out_shift[col];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int p = m0 + row;
-        float v = acc[im][in][r] + bv;
-        if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
-        acc[im][in][r] = v;
-        if (p < a.M) {
-          a.out[(size_t)p * a.Cout + col] = v;
-          s += v;
-        }
-      }
-    }
-    csum[in] = s;
-  }
-  if (EPI == EPI_STATS) {
-    // BatchNorm statistics of this tile, per output channel: (sum, M2) with M2 centred on
-    // the TILE mean (two reductions over the accumulators, which are still in registers).
-    // Centred partials are merged with Chan's formula in bn_finalize, so the variance never
-    // sees the E[y^2]-E[y]^2 cancellation.
-    float* red = smem;  // [WGM][BN] + [BN] means, re-uses the tile buffers (K loop is over)
-    const int rows_valid = min(BM, a.M - m0);
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
-    }
-    __syncthreads();
-    float* tsum = red + WGM * BN;   // [BN] tile column sums
-    for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      tsum[c] = v;
-      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)rows_valid;
-    float cm2[TN];
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
-      float q = 0.f;
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m0 + row < a.M) {
-            const float dlt = acc[im][in][r] - mean;
-            q = fmaf(dlt, dlt, q);
-          }
-        }
-      cm2[in] = q + __shfl_xor(q, 32, 64);
-    }
-    __syncthreads();  // everyone has read tsum/red
-#pragma unroll
-    for (int in = 0; in < TN; ++in)
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
-    __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
-    }
-  }
+  conv_epilogue<BM, BN, EPI, false>(a, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -299,22 +326,33 @@ conv3x3_igemm2_kernel(ConvArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
+  // buffer-load loaders, exactly as in conv3x3_igemm_kernel
   const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
-  int a_pix[AI], a_oh[AI], a_ow[AI];
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0,
+                                                        a.Cout * 9 * a.Cin * 4, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off[AI], a_taps[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int p = m0 + ld_row + 32 * i;
+    const int p = m0 + ld_row + 32 * i;
+    unsigned taps = 0;
     if (p < a.M) {
-      int r = p % HW;
-      a_pix[i] = p; a_oh[i] = r / a.W; a_ow[i] = r % a.W;
-    } else {
-      a_pix[i] = 0; a_oh[i] = -100000; a_ow[i] = 0;
-    }
-  }
-  const float* wrow[BI];
+      const int r = p % HW, oh = r / a.W, ow = r % a.W;
 #pragma unroll
-  for (int j = 0; j < BI; ++j)
-    wrow[j] = a.w + (size_t)(n0 + ld_row + 32 * j) * (9 * a.Cin) + ld_c4;
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) taps |= 1u << t;
+      }
+    }
+    a_taps[i] = taps;
+    a_off[i] = (unsigned)(p * a.Cin + ld_c4) * 4u;
+  }
+  unsigned w_off[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) w_off[j] = (unsigned)((n0 + ld_row + 32 * j) * 9 * a.Cin + ld_c4) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -341,12 +379,12 @@ conv3x3_igemm2_kernel(ConvArgs a) {
   auto load_tile = [&](int kt, Stage& S) {
     const int kn = kt0 + min(kt, nk - 1);
     const int cblk = kn / 9, tap = kn - cblk * 9;
-    const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
     const int c0 = cblk * BK + ld_c4;
-    const int koff = tap * a.Cin + cblk * BK;
-    const int doff = dh * a.W + dw;
+    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * BK) * 4u;
+    const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * BK) * 4u;
 #pragma unroll
-    for (int j = 0; j < BI; ++j) S.rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + koff);
+    for (int j = 0; j < BI; ++j)
+      S.rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
     if (IN_BN) {
       S.sc = *reinterpret_cast<const f32x4*>(a.in_scale + c0);
       S.sh = *reinterpret_cast<const f32x4*>(a.in_shift + c0);
@@ -354,11 +392,10 @@ conv3x3_igemm2_kernel(ConvArgs a) {
     unsigned ok = 0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
-      const bool v = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-      ok |= v ? (1u << i) : 0u;
-      const int pix = v ? a_pix[i] + doff : 0;
-      S.ra[i] = *reinterpret_cast<const f32x4*>(a.in + (size_t)pix * a.Cin + c0);
+      const bool v = (a_taps[i] >> tap) & 1u;
+      if (IN_BN) ok |= v ? (1u << i) : 0u;
+      S.ra[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, v ? a_off[i] : OOB, soff_in, 0));
     }
     S.ok = ok;
   };
@@ -374,8 +411,8 @@ conv3x3_igemm2_kernel(ConvArgs a) {
       if (IN_BN) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], S.sc[e], S.sh[e]), 0.f);
+        if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(Ab + (ld_row + 32 * i) * BKP + ld_c4) = v;
     }
 #pragma unroll
@@ -452,97 +489,137 @@ conv3x3_igemm2_kernel(ConvArgs a) {
   }
   if (kt < nk) iteration(std::integral_constant<int, 2>{}, kt, 0, S1, S0);  // odd tail
 
-  if (SPLITK) {
-    // raw partial sums; bias / BN / ReLU are applied by splitk_reduce_kernel
-    float* part = a.out + (size_t)blockIdx.y * a.M * a.Cout;
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const int col = n0 + wn * WTN + in * 32 + l31;
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (p < a.M) part[(size_t)p * a.Cout + col] = acc[im][in][r];
-        }
-    }
-    return;
-  }
+  conv_epilogue<BM, BN, EPI, SPLITK>(a, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
+}
 
-  // ---- epilogue (identical to variant 1)
-  float csum[TN];
+// ---------------------------------------------------------------------------
+// Variant 3 (raw inputs only: every dgrad, and the forward of units fed by a materialised
+// tensor): the tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`), no staging
+// registers, no ds_write instructions, no address VALU.  An LDS-DMA wave-instruction writes
+// 64 x 16 B = 1 KiB contiguously (base in M0 + lane*16), i.e. 8 rows of 128 B, so rows cannot
+// be padded; bank conflicts of the ds_read_b128 fragment reads are avoided with an XOR swizzle
+// applied on the SOURCE side: the lane that writes chunk position q of row r fetches logical
+// chunk q ^ ((r >> 1) & 7), and the fragment read of logical chunk c of row r goes to position
+// c ^ ((r >> 1) & 7).  Zero padding (image border, ragged M) is the hardware range check: a lane
+// whose tap falls outside the image gets an out-of-range offset and the DMA writes zeros
+// (probed on MI355X: tools/micro/lds_dma_probe.hip).
+template <int BM, int BN, int EPI, bool SPLITK = false>
+__global__ void __launch_bounds__(256)
+conv3x3_igemm_dma_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (LDS address-space casts do not parse there)
+  constexpr int WGN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave per K-tile (A, B)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][BM][32]
+  float* Bs = smem + 2 * BM * BK;  // [2][BN][32]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS base -> M0)
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W;
+
+  // ---- DMA source offsets: lane -> (row 8*wave + lane/8 of each 32-row group, chunk position lane%8)
+  const int lrow = wave * 8 + (lane >> 3);
+  const int c_log = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);  // logical chunk fetched by this lane
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0,
+                                                        a.Cout * 9 * a.Cin * 4, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off[AI], a_taps[AI];
 #pragma unroll
-  for (int in = 0; in < TN; ++in) {
-    const int col = n0 + wn * WTN + in * 32 + l31;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-    float osc = 1.f, osh = 0.f;
-    if (EPI == EPI_BNRELU) { osc = a.out_scale[col]; osh = a.out_shift[col]; }
-    float s = 0.f;
+  for (int i = 0; i < AI; ++i) {
+    const int p = m0 + lrow + 32 * i;
+    unsigned taps = 0;
+    if (p < a.M) {
+      const int r = p % HW, oh = r / a.W, ow = r % a.W;
 #pragma unroll
-    for (int im = 0; im < TM; ++im) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int p = m0 + row;
-        float v = acc[im][in][r] + bv;
-        if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
-        acc[im][in][r] = v;
-        if (p < a.M) {
-          a.out[(size_t)p * a.Cout + col] = v;
-          s += v;
-        }
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) taps |= 1u << t;
       }
     }
-    csum[in] = s;
+    a_taps[i] = taps;
+    a_off[i] = (unsigned)(p * a.Cin + c_log * 4) * 4u;
   }
-  if (EPI == EPI_STATS) {
-    float* red = smem;
-    const int rows_valid = min(BM, a.M - m0);
+  unsigned w_off[BI];
 #pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
-    }
-    __syncthreads();
-    float* tsum = red + WGM * BN;
-    for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
+  for (int j = 0; j < BI; ++j) w_off[j] = (unsigned)((n0 + lrow + 32 * j) * 9 * a.Cin + c_log * 4) * 4u;
+
+  // ---- fragment-read offsets (floats): row wm*WTM + im*32 + l31, position (2*ks + half) ^ x
+  const int x = (l31 >> 1) & 7;
+  int frag_pos[BK / 8];
 #pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      tsum[c] = v;
-      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)rows_valid;
-    float cm2[TN];
+  for (int ks = 0; ks < BK / 8; ++ks) frag_pos[ks] = ((2 * ks + half) ^ x) * 4;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
-      float q = 0.f;
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m0 + row < a.M) {
-            const float dlt = acc[im][in][r] - mean;
-            q = fmaf(dlt, dlt, q);
-          }
-        }
-      cm2[in] = q + __shfl_xor(q, 32, 64);
-    }
-    __syncthreads();
+  for (int im = 0; im < TM; ++im)
 #pragma unroll
     for (int in = 0; in < TN; ++in)
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
-    __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  const int nk_total = 9 * (a.Cin / BK);
+  const int kt0 = SPLITK ? (int)blockIdx.y * a.kt_per_split : 0;
+  const int nk = SPLITK ? min(a.kt_per_split, nk_total - kt0) : nk_total;
+
+  auto dma_tile = [&](int kt, int buf) {
+    const int kn = kt0 + min(kt, nk - 1);
+    const int cblk = kn / 9, tap = kn - cblk * 9;
+    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * BK) * 4u;
+    const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * BK) * 4u;
+    float* Ab = As + buf * BM * BK + wave * 8 * BK;
+    float* Bb = Bs + buf * BN * BK + wave * 8 * BK;
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(Bb + j * 32 * BK), 16, w_off[j], soff_w, 0, 0);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool ok = (a_taps[i] >> tap) & 1u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(Ab + i * 32 * BK), 16,
+                                               ok ? a_off[i] : OOB, soff_in, 0, 0);
     }
+  };
+
+  dma_tile(0, 0);
+  __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of a barrier)
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    dma_tile(kt + 1, cur ^ 1);  // clamped at the end: a redundant copy of the last tile, never read
+    const float* Ab = As + cur * BM * BK + (wm * WTM + l31) * BK;
+    const float* Bb = Bs + cur * BN * BK + (wn * WTN + l31) * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+        af[im] = *reinterpret_cast<const f32x4*>(Ab + im * 32 * BK + frag_pos[ks]);
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+        bf[in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BK + frag_pos[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+    }
+    __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading tile kt
+    cur ^= 1;
   }
+  conv_epilogue<BM, BN, EPI, SPLITK>(a, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
+#endif
 }
 
 // out[p][c] = epi(bias[c] + sum_s partial[s][p][c]); fixed summation order (deterministic)
@@ -583,8 +660,10 @@ static int g_conv_impl = 0;           // main-loop variant of the non-split laun
                                       // (default: fastest end to end in in-process A/B), 1 two stages,
                                       // 2 two stages + sched_group_barrier interleave
 static int g_conv_dbg = 0;
+static int g_conv_dma = 1;             // raw-input convolutions fetch their tiles by LDS-DMA (variant 3)
 static int g_splitk = 1;              // 0: never split K; 1: split K when the grid would not fill the chip
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
+static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_tune_set(const char* key, int value) {
   if (!key) return TDX_E_BADARG;
@@ -592,6 +671,8 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "conv_impl")) { g_conv_impl = value < 0 || value > 2 ? 0 : value; return 0; }
   if (!strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
+  if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
+  if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
   return TDX_E_BADARG;
 }
@@ -624,6 +705,20 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
   const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU
                   : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS
                                                  : EPI_PLAIN;
+#define TDX_LAUNCH_DMA(EPI_)                                                                \
+  do {                                                                                      \
+    auto kern = conv3x3_igemm_dma_kernel<BM, BN, EPI_>;                                     \
+    const size_t lds_dma = (size_t)2 * (BM + BN) * BK * sizeof(float);                      \
+    kern<<<grid, 256, lds_dma, st>>>(a);                                                    \
+  } while (0)
+  if (!in_bn && g_conv_dma) {
+    if (epi == EPI_BNRELU) TDX_LAUNCH_DMA(EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH_DMA(EPI_STATS);
+    else TDX_LAUNCH_DMA(EPI_PLAIN);
+    TDX_CHECK_LAUNCH();
+    return 0;
+  }
+#undef TDX_LAUNCH_DMA
 #define TDX_LAUNCH(INBN, EPI_)                                                              \
   do {                                                                                      \
     auto kern = g_conv_impl == 2 ? conv3x3_igemm2_kernel<BM, BN, INBN, EPI_, false, true>   \
@@ -1002,6 +1097,10 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
   WgradCfg c;
   c.bm = (cout % 128 == 0) ? 128 : 64;
   c.bn = (cin % 128 == 0) ? 128 : 64;
+  // Deep layers have many weight tiles but few pixels: 128x128 tiles would need ~15 pixel splits
+  // to fill the chip, i.e. 15 partial copies of a 9.4 MB gradient written and re-read by the
+  // reduce (140 MB per layer).  64x64 tiles give 4x the workgroups from the weights alone.
+  if (g_wgrad_small && (int64_t)cout * cin >= (1 << 17) && M <= 16384) { c.bm = 64; c.bn = 64; }
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
   int64_t s = (g_wgrad_target + tiles - 1) / tiles;
   int64_t smax = (M + 255) / 256;
