@@ -783,6 +783,8 @@ static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scr
   const size_t lds = (size_t)2 * (64 + 64) * BKP * sizeof(float);
   dim3 grid(cdiv(a.M, 64) * a.tilesN, splits);
   if (in_bn) conv3x3_igemm2_kernel<64, 64, true, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
+  else if (g_conv_dma)
+    conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
   else conv3x3_igemm2_kernel<64, 64, false, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
   TDX_CHECK_LAUNCH();
   const int64_t n4 = (int64_t)a.M * a.Cout / 4;
@@ -1089,6 +1091,152 @@ conv3x3_wgrad_kernel(WgradArgs a) {
       }
 }
 
+// wgrad with both operands fetched by LDS-DMA (raw input only).  The [32 pixels][channels]
+// tiles are already linear in LDS (a pixel row is 256 or 512 contiguous bytes and the fragment
+// reads are lane-contiguous ds_read_b64/b32), so no swizzle is needed: one DMA wave-instruction
+// lands 1 KiB = 2 (or 4) whole pixel rows.  Ragged pixel ranges and image borders are zero
+// filled by the buffer range check as in conv3x3_wgrad_kernel.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_dma_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WGN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ACH = BM / 4, BCH = BN / 4;
+  constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;  // pixel rows per pass of the 256 threads
+  constexpr int AI = 32 / AROWS, BI = 32 / BROWS;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][32][BM]
+  float* Bs = smem + 2 * 32 * BM;  // [2][32][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int L = blockIdx.x;
+  const int g = (L / 72) * 8 + (L % 8);
+  const int tap = (L % 72) / 8;
+  if (g >= a.groups) return;
+  const int tiles = a.tilesCo * a.tilesCi;
+  const int split = g / tiles, tl = g % tiles;
+  const int tile_co = tl / a.tilesCi, tile_ci = tl % a.tilesCi;
+  const int co0 = tile_co * BM, ci0 = tile_ci * BN;
+  const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+  const int HW = a.H * a.W;
+  const int p_lo = split * a.chunk;
+  const int p_hi = min(p_lo + a.chunk, a.M);
+  const int nk = (p_hi - p_lo + 31) / 32;
+
+  const int a_c4 = (tid % ACH) * 4, a_r0 = tid / ACH;
+  const int b_c4 = (tid % BCH) * 4, b_r0 = tid / BCH;
+  constexpr unsigned OOB = 0x80000000u;
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0,
+                                                         (int)((int64_t)p_hi * a.Cout * 4), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  unsigned a_off[AI], b_off[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) a_off[i] = (unsigned)((a_r0 + AROWS * i) * a.Cout + co0 + a_c4) * 4u;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) b_off[i] = (unsigned)((b_r0 + BROWS * i) * a.Cin + ci0 + b_c4) * 4u;
+  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * 4u;
+  int b_oh[BI], b_ow[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = (p_lo + b_r0 + BROWS * i) % HW;
+    b_oh[i] = r / a.W;
+    b_ow[i] = r % a.W;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  // tiles are requested strictly in order 0, 1, 2, ...; `first` skips the coordinate advance
+  auto dma_tile = [&](int kt, int buf, bool advance) {
+    const int pbase = p_lo + kt * 32;
+    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 4u;
+    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 4u + tap_shift;
+    // LDS destination of this wave's instruction i: rows (wave*64/ACH + AROWS*i) .. , lane-linear
+    float* Ab = As + buf * 32 * BM + wave * 256;
+    float* Bb = Bs + buf * 32 * BN + wave * 256;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (lds_ptr_t)(Ab + i * AROWS * BM), 16, a_off[i], soff_a, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if (advance) {
+        int ow = b_ow[i] + a.adv_s, oh = b_oh[i] + a.adv_q;
+        if (ow >= a.W) { ow -= a.W; oh += 1; }
+        if (oh >= 2 * a.H) oh -= 2 * a.H;
+        if (oh >= a.H) oh -= a.H;
+        b_ow[i] = ow;
+        b_oh[i] = oh;
+      }
+      const int ih = b_oh[i] + dh, iw = b_ow[i] + dw;
+      const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(Bb + i * BROWS * BN), 16,
+                                               ok ? b_off[i] : OOB, soff_b, 0, 0);
+    }
+  };
+
+  if (nk > 0) dma_tile(0, 0, false);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1, true);
+    const float* Ab = As + cur * 32 * BM + half * BM + wm * WTM + TM * l31;
+    const float* Bb = Bs + cur * 32 * BN + half * BN + wn * WTN + TN * l31;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      float af[TM], bf[TN];
+      if (TM == 2) {
+        float2 v = *reinterpret_cast<const float2*>(Ab + ks * 2 * BM);
+        af[0] = v.x; af[TM - 1] = v.y;
+      } else {
+        af[0] = Ab[ks * 2 * BM];
+      }
+      if (TN == 2) {
+        float2 v = *reinterpret_cast<const float2*>(Bb + ks * 2 * BN);
+        bf[0] = v.x; bf[TN - 1] = v.y;
+      } else {
+        bf[0] = Bb[ks * 2 * BN];
+      }
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im], bf[in], acc[im][in], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + wm * WTM + TM * i + im;
+        const int ci = ci0 + wn * WTN + TN * l31 + in;
+        slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[im][in][r];
+      }
+#endif
+}
+
 struct WgradCfg {
   int bm, bn, splits, chunk;
 };
@@ -1123,6 +1271,7 @@ static int launch_wgrad(const WgradArgs& a, int splits, bool in_bn, hipStream_t 
   const size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
   dim3 grid((unsigned)(((int64_t)a.groups + 7) / 8 * 72));
   if (in_bn) conv3x3_wgrad_kernel<BM, BN, true><<<grid, 256, lds, st>>>(a);
+  else if (g_conv_dma) conv3x3_wgrad_dma_kernel<BM, BN><<<grid, 256, lds, st>>>(a);
   else conv3x3_wgrad_kernel<BM, BN, false><<<grid, 256, lds, st>>>(a);
   TDX_CHECK_LAUNCH();
   return 0;
