@@ -91,6 +91,20 @@ def conv_roofline(B: int, reps: int = 5):
     return rows, tot_flop, tot_ms, n_launch
 
 
+def roofline_block(B: int):
+    rows, flop, ms, nl = conv_roofline(B)
+    ach = flop / ms / 1e9
+    return {
+        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "kernel": "conv3x3_igemm_dma_kernel / conv3x3_igemm_kernel (fwd, dgrad) + "
+                  "conv3x3_wgrad_dma_kernel / conv3x3_wgrad_kernel + wgrad split reduce excluded",
+        "launches_per_step": nl, "conv_ms_per_step": round(ms, 3), "avg_launch_us": round(ms / nl * 1e3, 1),
+        "algorithmic_gflop_per_step": round(flop / 1e9, 1),
+        "per_launch": rows,
+    }
+
+
 def cpu_baseline(batch: int = 64, steps: int = 6, threads: int = 16):
     """The CPU oracle (port of diffusion.py:214-236: q_sample + fwd + MSE + bwd + Adam) on this
     host's cores; bounded sample, reported beside the GPU number, never the target."""
@@ -139,7 +153,13 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu baseline / sampling legs")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the per-launch conv timing leg (for rocprofv3 cross-checks)")
     args = ap.parse_args()
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        print(json.dumps({"roofline": roofline_block(PER_GPU_BATCH)}))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -204,17 +224,9 @@ def main():
             "train_tflops_per_gpu": round(value / world * TRAIN_FLOP_PER_IMAGE / 1e12, 2),
         }
         if not args.no_extras and world == 1:
-            rows, flop, ms, nl = conv_roofline(PER_GPU_BATCH)
-            ach = flop / ms / 1e9
-            res["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "conv3x3_igemm2_kernel (fwd, dgrad) + conv3x3_wgrad_kernel",
-                "launches_per_step": nl, "conv_ms_per_step": round(ms, 3),
-                "algorithmic_gflop_per_step": round(flop / 1e9, 1),
-                "whole_step_frac": round(value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "per_launch": rows,
-            }
+            res["roofline"] = roofline_block(PER_GPU_BATCH)
+            res["roofline"]["whole_step_frac"] = round(
+                value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             res["cpu_baseline"] = cpu_baseline()
             model.eval()
             res["sample"] = {"unit": "s per 1000-step chain (HIP-graph replay, in-kernel Philox noise)",

@@ -167,7 +167,12 @@ conv3x3_igemm_kernel(ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  // Workgroup id -> tile, XCD-aware: ids are dealt round-robin over the 8 XCDs, so the tilesN
+  // column tiles of one row tile (which read the same input rows) are given ids that differ by
+  // multiples of 8 inside a block of 8*tilesN consecutive ids: same XCD, same L2, close in time.
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;  // grid is padded to a multiple of 8 row tiles
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
@@ -322,7 +327,12 @@ conv3x3_igemm2_kernel(ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  // Workgroup id -> tile, XCD-aware: ids are dealt round-robin over the 8 XCDs, so the tilesN
+  // column tiles of one row tile (which read the same input rows) are given ids that differ by
+  // multiples of 8 inside a block of 8*tilesN consecutive ids: same XCD, same L2, close in time.
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;  // grid is padded to a multiple of 8 row tiles
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
@@ -522,7 +532,12 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS base -> M0)
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tile_n = blockIdx.x % a.tilesN, tile_m = blockIdx.x / a.tilesN;
+  // Workgroup id -> tile, XCD-aware: ids are dealt round-robin over the 8 XCDs, so the tilesN
+  // column tiles of one row tile (which read the same input rows) are given ids that differ by
+  // multiples of 8 inside a block of 8*tilesN consecutive ids: same XCD, same L2, close in time.
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;  // grid is padded to a multiple of 8 row tiles
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
@@ -700,7 +715,7 @@ static TileCfg pick_tile(int64_t M, int cout) {
 template <int BM, int BN>
 static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-  const int grid = cdiv(a.M, BM) * a.tilesN;
+  const int grid = (cdiv(a.M, BM) + 7) / 8 * 8 * a.tilesN;
   const bool in_bn = flags & TDX_CONV_IN_BNRELU;
   const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU
                   : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS
@@ -781,7 +796,7 @@ static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scr
   a.splits = splits;
   a.kt_per_split = per;
   const size_t lds = (size_t)2 * (64 + 64) * BKP * sizeof(float);
-  dim3 grid(cdiv(a.M, 64) * a.tilesN, splits);
+  dim3 grid((cdiv(a.M, 64) + 7) / 8 * 8 * a.tilesN, splits);
   if (in_bn) conv3x3_igemm2_kernel<64, 64, true, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
   else if (g_conv_dma)
     conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
