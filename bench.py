@@ -167,13 +167,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; (a rehearsal with more ranks than GPUs - gloo only - wraps around)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "RANK" in os.environ      # torch.distributed.run, even with 1 rank
+    backend = os.environ.get("TDX_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
     from tiny_diffusion_amd.train import TrainStep
@@ -205,6 +211,14 @@ def main():
     loss_v = loss.item()
     if not (loss_v == loss_v) or loss_v > 1e3:
         raise SystemExit(f"training diverged in the benchmark: loss {loss_v}")
+    if world > 1:
+        # outside the timed region: replicas must still hold identical parameters
+        probe = torch.stack([ts.flat_param.double().sum(), ts.flat_param.double().pow(2).sum()])
+        lo, hi = probe.clone(), probe.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"data-parallel replicas diverged: {lo.tolist()} vs {hi.tolist()}")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
