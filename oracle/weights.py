@@ -113,3 +113,86 @@ def state_dict_sha256(sd) -> str:
         if v.dtype == torch.float32:
             h.update(v.contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+# --------------------------------------------------------------------------
+# conditional_diffusion_laion.py NoiseModel: latent UNet on
+# (4,32,32) with 768-d sinusoidal time embedding + additive text conditioning
+# --------------------------------------------------------------------------
+LAION_TIME_DIM = 768
+_LAION_STAGES = [
+    ("enc1", 32, 64),
+    ("enc2", 64, 128),
+    ("enc3", 128, 256),
+    ("dec3", 512, 256),
+    ("dec2", 384, 128),
+    ("dec1", 192, 64),
+]
+
+
+def key_shapes_laion(time_dim: int = LAION_TIME_DIM):
+    """Ordered (key, shape, kind) == state_dict() of the reference's LAION NoiseModel
+    (conditional_diffusion_laion.py:234-301)."""
+    out = []
+
+    def conv(name, cin, cout, k):
+        out.append((f"{name}.weight", (cout, cin, k, k), "conv_w"))
+        out.append((f"{name}.bias", (cout,), "bias"))
+
+    def bn(name, c):
+        out.append((f"{name}.weight", (c,), "bn_w"))
+        out.append((f"{name}.bias", (c,), "bn_b"))
+        out.append((f"{name}.running_mean", (c,), "bn_rm"))
+        out.append((f"{name}.running_var", (c,), "bn_rv"))
+        out.append((f"{name}.num_batches_tracked", (), "bn_nbt"))
+
+    out.append(("time_mlp.0.weight", (time_dim, time_dim), "lin_w"))
+    out.append(("time_mlp.0.bias", (time_dim,), "bias"))
+    out.append(("time_mlp.2.weight", (time_dim, time_dim), "lin_w"))
+    out.append(("time_mlp.2.bias", (time_dim,), "bias"))
+    conv("initial_conv", 4, 32, 3)
+    for name, cin, cout in _LAION_STAGES[:3]:
+        conv(f"{name}.0", cin, cout, 3)
+        bn(f"{name}.1", cout)
+        conv(f"{name}.3", cout, cout, 3)
+        bn(f"{name}.4", cout)
+    conv("bottleneck.0", 256, 256, 3)
+    bn("bottleneck.1", 256)
+    for name, cin, cout in _LAION_STAGES[3:]:
+        conv(f"{name}.0", cin, cout, 3)
+        bn(f"{name}.1", cout)
+        conv(f"{name}.3", cout, cout, 3)
+        bn(f"{name}.4", cout)
+    conv("final_conv", 64, 4, 3)
+    conv("time_proj1", time_dim, 64, 1)
+    conv("time_proj2", time_dim, 128, 1)
+    conv("time_proj3", time_dim, 256, 1)
+    return out
+
+
+def make_state_dict_laion(seed: int = 0):
+    """Seeded reference-format state_dict of the LAION NoiseModel (same recipe as
+    make_state_dict: portable numpy legacy RNG, non-trivial BN statistics)."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape, kind in key_shapes_laion():
+        if kind in ("conv_w", "lin_w"):
+            fan_in = int(np.prod(shape[1:]))
+            a = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif kind == "bias":
+            a = rs.standard_normal(shape) * 0.01
+        elif kind == "bn_w":
+            a = 1.0 + rs.standard_normal(shape) * 0.1
+        elif kind == "bn_b":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rm":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rv":
+            a = 1.0 + np.abs(rs.standard_normal(shape) * 0.1)
+        elif kind == "bn_nbt":
+            sd[key] = torch.tensor(1, dtype=torch.int64)
+            continue
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return sd

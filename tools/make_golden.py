@@ -46,6 +46,12 @@ def load_reference(script):
     tv.datasets = _stub("torchvision.datasets")
     tv.utils = _stub("torchvision.utils")
     _stub("wandb")
+    if "laion" in script:
+        # data / pretrained-model packages of the LAION script: referenced only by its
+        # downloader, CLIP and SD-VAE code, never by NoiseModel / ForwardProcess
+        _stub("datasets", load_dataset=None)
+        _stub("diffusers", AutoencoderKL=None)
+        _stub("transformers", CLIPTextModel=None, CLIPTokenizer=None)
     spec = importlib.util.spec_from_file_location(
         "ref_" + script.replace(".py", ""), os.path.join(REF, script)
     )
@@ -253,6 +259,59 @@ def schedule_fixture(mod):
              sqrt_1mac=torch.sqrt(1.0 - fp.alphas_cumprod).numpy())
 
 
+def laion_fixtures(mod):
+    """conditional_diffusion_laion.py NoiseModel on synthetic (4,32,32) latents + 768-d
+    conditioning vectors (CLIP and the SD-VAE are not available offline)."""
+    from oracle.weights import make_state_dict_laion
+
+    sd = make_state_dict_laion(0)
+    rs = np.random.RandomState(4242)
+    B = 8
+    x0 = rs.standard_normal((B, 4, 32, 32)).astype(np.float32)
+    noise = rs.standard_normal((B, 4, 32, 32)).astype(np.float32)
+    t = rs.randint(0, 1000, size=(B,)).astype(np.int64); t[0], t[1] = 0, 999
+    cond = rs.standard_normal((B, 768)).astype(np.float32)
+    fp = mod.ForwardProcess()
+    tt, nt, ct = torch.from_numpy(t), torch.from_numpy(noise), torch.from_numpy(cond)
+    x_t = (torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * torch.from_numpy(x0)
+           + torch.sqrt(1 - fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * nt)
+    d = dict(x_t=x_t.numpy(), noise=noise, t=t, cond=cond,
+             sinusoid=mod.get_timestep_embedding(torch.tensor([0, 1, 999]), 768).numpy())
+    for mode in ("train", "eval"):
+        model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.train(mode == "train")
+        with torch.no_grad():
+            eps = model(x_t, tt, ct)
+        d[f"eps_{mode}"] = eps.numpy()
+        d[f"loss_{mode}"] = np.float64(F.mse_loss(eps, nt).item())
+        if mode == "train":
+            d.update({"buf__" + k: v for k, v in bn_buffers(model).items()})
+    model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.train()
+    loss = F.mse_loss(model(x_t, tt, ct), nt); loss.backward()
+    for k, p in model.named_parameters():
+        g = p.grad.detach().contiguous().view(-1); kk = k.replace(".", "__")
+        d[f"gnorm__{kk}"] = np.float64(g.double().norm().item())
+        d[f"ghead__{kk}"] = g[:64].numpy().copy()
+    # reverse chain (reference loop conditional_diffusion_laion.py:574-587; its torch.compile
+    # wrapper and the VAE decode are outside the path), T = 10, recorded noise
+    T, n = 10, 2
+    fpT = mod.ForwardProcess(num_timesteps=T)
+    model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.eval()   # pristine BN buffers
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(n, 4, 32, 32, generator=g); x_T = x.clone()
+    zs = np.zeros((T, n, 4, 32, 32), np.float32)
+    cs = ct[:n]
+    with torch.no_grad():
+        for step in reversed(range(T)):
+            eps = model(x, torch.full((n,), step, dtype=torch.long), cs)
+            z = torch.randn(x.shape, generator=g) if step > 0 else torch.zeros_like(x)
+            zs[step] = z.numpy()
+            alpha, ac, beta = fpT.alphas[step], fpT.alphas_cumprod[step], fpT.betas[step]
+            x = (1 / torch.sqrt(alpha)) * (x - ((1 - alpha) / torch.sqrt(1 - ac)) * eps) + torch.sqrt(beta) * z
+    d.update(chain_x_T=x_T.numpy(), chain_zs=zs, chain_final=x.numpy(), chain_T=T)
+    np.savez(os.path.join(OUT, "laion_B8.npz"), **d)
+    print("laion_B8 loss train/eval", d["loss_train"], d["loss_eval"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -278,6 +337,7 @@ def main():
     sample_fixture(unc, False, 20, 4, keep=[19, 10, 1, 0])
     sample_fixture(con, True, 20, 4, keep=[19, 10, 1, 0])
     sample_fixture(unc, False, 1000, 4, keep=[999, 750, 500, 250, 1, 0])
+    laion_fixtures(load_reference("conditional_diffusion_laion.py"))
 
 
 if __name__ == "__main__":
