@@ -217,15 +217,24 @@ typedef struct tdx_unet tdx_unet;
 
 /* num_classes == 0: unconditional (diffusion.py); > 0: class-conditional. */
 int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes);
+/* kind TDX_UNET_MNIST: the 1x28x28 NoiseModel above (tdx_unet_create == kind 0);
+ * kind TDX_UNET_LAION: NoiseModel of conditional_diffusion_laion.py:234-332 - 4x32x32 latents,
+ *   widths 32..256, sinusoidal timestep embedding + Linear(768,768) MLP, additive 768-d text
+ *   conditioning (num_classes must be 0).  Same parameter/buffer slot numbering; slot
+ *   TDX_P_CLASS_EMB is unused, TDX_P_TE0_W is (768,768). */
+enum { TDX_UNET_MNIST = 0, TDX_UNET_LAION = 1 };
+int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes);
 int tdx_unet_destroy(tdx_unet* u);
 size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode);
 
-/* eps_hat = NoiseModel.forward(x, t[, y]) (diffusion.py:109-162).
+/* eps_hat = NoiseModel.forward(x, t[, cond]) (diffusion.py:109-162,
+ * conditional_diffusion.py:115-172, conditional_diffusion_laion.py:304-332).
  *   params: TDX_P_COUNT device pointers (reference layout); buffers: TDX_B_COUNT.
- *   x (B,1,28,28) fp32; t (B,) int64; y (B,) int64 or NULL; out (B,1,28,28).
+ *   kind MNIST: x (B,1,28,28) fp32; t (B,) int64; cond = y (B,) int64 labels or NULL; out (B,1,28,28).
+ *   kind LAION: x (B,4,32,32) fp32; t (B,) int64; cond = text_embeds (B,768) fp32; out (B,4,32,32).
  * In TRAIN mode the BN running buffers are updated in place. */
 int tdx_unet_forward(tdx_unet* u, const void* const* params, void* const* buffers,
-                     const float* x, const int64_t* t, const int64_t* y, float* out,
+                     const float* x, const int64_t* t, const void* cond, float* out,
                      void* workspace, size_t workspace_bytes, int batch, int mode,
                      tdx_stream_t stream);
 

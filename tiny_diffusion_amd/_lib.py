@@ -86,6 +86,7 @@ _SIGS = {
     "tdx_bilinear_ac_bwd": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _ptr]),
     "tdx_unet_create": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int]),
+    "tdx_unet_create_ex": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int]),
     "tdx_unet_destroy": (C.c_int, [_ptr]),
     "tdx_unet_workspace_bytes": (C.c_size_t, [_ptr, C.c_int, C.c_int]),
     "tdx_unet_forward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int,

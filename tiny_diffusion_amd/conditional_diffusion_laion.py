@@ -1,0 +1,73 @@
+"""Drop-in for the hot path of the reference's ``conditional_diffusion_laion.py``
+(text-conditioned latent DDPM): the same ``get_timestep_embedding``,
+``NoiseModel(time_dim=768)`` with ``forward(x, t, text_embeds)``, ``ForwardProcess`` and
+``sample(noise_model, diffusion, device, text_embeds, vae, scaling_factor)`` contracts
+(conditional_diffusion_laion.py:222-232, 234-332, 335-358, 561-600).
+
+Only the noise predictor and the reverse loop run on libtdx; the pretrained VAE and CLIP
+text encoder the reference pulls from ``diffusers`` / ``transformers`` are external models
+and stay whatever object the caller passes in (out of scope)."""
+from __future__ import annotations
+
+import torch
+
+from .schedule import ForwardProcess as _ForwardProcess, sample_loop
+from .unet import ARCH_LAION, NoiseModelBase
+
+__all__ = ["NoiseModel", "ForwardProcess", "get_timestep_embedding", "sample", "postprocess_images"]
+
+TIME_DIM = ARCH_LAION.time_dim
+
+
+def get_timestep_embedding(timesteps, embedding_dim):
+    """conditional_diffusion_laion.py:222-232.  Host-side utility kept for API parity (the
+    model evaluates the same expression inside its time-embedding kernels)."""
+    half_dim = embedding_dim // 2
+    frequencies = torch.exp(
+        -torch.log(torch.tensor(10000.0))
+        * torch.arange(half_dim, dtype=torch.float32, device=timesteps.device) / (half_dim - 1))
+    embeddings = timesteps[:, None].float() * frequencies[None, :]
+    embeddings = torch.cat([torch.sin(embeddings), torch.cos(embeddings)], dim=-1)
+    if embedding_dim % 2 == 1:
+        embeddings = torch.cat([embeddings, torch.zeros_like(embeddings[:, :1])], dim=-1)
+    return embeddings
+
+
+class NoiseModel(NoiseModelBase):
+    """eps_theta(x_t, t, text_embeds) on (4,32,32) latents: sinusoidal embedding -> time_mlp,
+    + text_embeds, UNet 32/64/128/256 (conditional_diffusion_laion.py:234-332)."""
+
+    def __init__(self, time_dim: int = TIME_DIM):
+        super().__init__(time_dim=time_dim, num_classes=0, arch=ARCH_LAION)
+
+    def forward(self, x, t, text_embeds):
+        return self._forward_impl(x, t, text_embeds)
+
+
+class ForwardProcess(_ForwardProcess):
+    """conditional_diffusion_laion.py:335-358 (q_sample(device, x_0, t) draws its own noise)."""
+
+
+def postprocess_images(decoded):
+    """(decoded / 2 + 0.5).clamp(0, 1) with NaN/Inf replaced by zeros, fp32
+    (conditional_diffusion_laion.py:590-599)."""
+    images = (decoded / 2 + 0.5).clamp(0, 1)
+    images = torch.where(torch.logical_or(torch.isnan(images), torch.isinf(images)),
+                         torch.zeros_like(images), images)
+    return images.to(torch.float32)
+
+
+@torch.no_grad()
+def sample(noise_model: NoiseModel, diffusion: ForwardProcess, device, text_embeds=None, vae=None,
+           scaling_factor=1.0, **kw):
+    """conditional_diffusion_laion.py:561-600: the reverse loop over latents, then
+    ``vae.decode(x / scaling_factor).sample`` and the image post-processing.  With
+    ``vae=None`` the latents are returned (the decoder is an external pretrained model)."""
+    if text_embeds is None:
+        raise ValueError("Text embeddings must be provided for conditional generation.")
+    n_samples = text_embeds.shape[0]
+    x = sample_loop(noise_model, diffusion, device, n_samples, text_embeds, **kw)
+    if vae is None:
+        return x
+    decoded = vae.decode(x / scaling_factor).sample
+    return postprocess_images(decoded)

@@ -1317,34 +1317,43 @@ extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_sla
 }
 
 // sum the split-K slabs in a fixed order and write the OIHW gradient
+// (cin = channels as stored in the slabs; only the first cin_real of them exist in dw)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                    int splits, int cout, int cin) {
+                                    int splits, int cout, int cin, int cin_real) {
   const int64_t n = (int64_t)cout * 9 * cin;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    if (ci >= cin_real) continue;
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
-    const int ci = (int)(i % cin);
     const int tap = (int)((i / cin) % 9);
     const int co = (int)(i / ((int64_t)9 * cin));
-    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+    dw[((size_t)co * cin_real + ci) * 9 + tap] = s;
   }
 }
 
-extern "C" int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, int cout,
-                                        int cin, tdx_stream_t stream) {
-  if (!dw_slabs || !dw_oihw || splits <= 0 || cout <= 0 || cin <= 0) return TDX_E_BADARG;
+int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int splits, int cout, int cin,
+                                 int cin_real, tdx_stream_t stream) {
+  if (!dw_slabs || !dw_oihw || splits <= 0 || cout <= 0 || cin <= 0 || cin_real <= 0 || cin_real > cin)
+    return TDX_E_BADARG;
   int64_t n = (int64_t)cout * 9 * cin;
   int grid = (int)((n + 255) / 256);
   if (grid > 4096) grid = 4096;
-  wgrad_reduce_kernel<<<grid, 256, 0, to_stream(stream)>>>(dw_slabs, dw_oihw, splits, cout, cin);
+  wgrad_reduce_kernel<<<grid, 256, 0, to_stream(stream)>>>(dw_slabs, dw_oihw, splits, cout, cin, cin_real);
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
+extern "C" int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, int cout,
+                                        int cin, tdx_stream_t stream) {
+  return tdx_conv3x3_wgrad_reduce_pad(dw_slabs, dw_oihw, splits, cout, cin, cin, stream);
+}
+
 // ----------------------------------------------------------------- packing
+// (the packs hold cin channels; channels >= cin_real are zero - a zero-padded input tensor)
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf,
-                                    float* __restrict__ wd, int cout, int cin) {
+                                    float* __restrict__ wd, int cout, int cin, int cin_real) {
   const int64_t n = (int64_t)cout * cin * 9;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -1352,20 +1361,25 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     const int ci = (int)(i % cin);
     const int tap = (int)((i / cin) % 9);
     const int co = (int)(i / ((int64_t)9 * cin));
-    const float v = w[((size_t)co * cin + ci) * 9 + tap];
+    const float v = ci < cin_real ? w[((size_t)co * cin_real + ci) * 9 + tap] : 0.f;
     if (wf) wf[i] = v;
     // dgrad pack [ci][8-tap][co]: dIn[p][ci] = sum dy[p + tap'][co] * W[co][ci][flip(tap')]
     if (wd) wd[((size_t)ci * 9 + (8 - tap)) * cout + co] = v;
   }
 }
 
-extern "C" int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout,
-                                int cin, tdx_stream_t stream) {
-  if (!w_oihw || cout <= 0 || cin <= 0) return TDX_E_BADARG;
+int tdx_pack_conv3x3_pad(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout, int cin_real,
+                         int cin, tdx_stream_t stream) {
+  if (!w_oihw || cout <= 0 || cin <= 0 || cin_real <= 0 || cin_real > cin) return TDX_E_BADARG;
   int64_t n = (int64_t)cout * cin * 9;
   int grid = (int)((n + 255) / 256);
   if (grid > 4096) grid = 4096;
-  pack_conv3x3_kernel<<<grid, 256, 0, to_stream(stream)>>>(w_oihw, w_fwd, w_dgrad, cout, cin);
+  pack_conv3x3_kernel<<<grid, 256, 0, to_stream(stream)>>>(w_oihw, w_fwd, w_dgrad, cout, cin, cin_real);
   TDX_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout,
+                                int cin, tdx_stream_t stream) {
+  return tdx_pack_conv3x3_pad(w_oihw, w_fwd, w_dgrad, cout, cin, cin, stream);
 }

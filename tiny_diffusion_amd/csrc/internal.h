@@ -5,19 +5,30 @@
 int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t st);
 int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
                         hipStream_t st);
+// initial_conv: NCHW model input (cin = 1 | 4) -> channels-last, 64 channels stored of which the
+// first cout_real (64 | 32) are real; final_conv: channels-last 64 -> NCHW cout (1 | 4)
 int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                         int W, hipStream_t st);
-int tdx_initial_conv_wgrad_blocks(int B, int H, int W);
+                         int W, int cin, int cout_real, hipStream_t st);
+int tdx_small_conv_wgrad_blocks(int B, int H, int W);
+int tdx_small_conv_partial_width(void);
 int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
-                           int B, int H, int W, hipStream_t st);
+                           int B, int H, int W, int cin, int cout_real, hipStream_t st);
 int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
-                       int W, hipStream_t st);
+                       int W, int cout, hipStream_t st);
 int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
-                         hipStream_t st);
+                         int cout, hipStream_t st);
 int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
-                         int B, int H, int W, hipStream_t st);
-int tdx_time_embed_fwd(const int64_t* t, const int64_t* y, const float* const* P, float* pre,
-                       float* emb, float* t1, float* t2, float* t3, int B, hipStream_t st);
-int tdx_time_embed_bwd(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
-                       const float* pre, const float* emb, const float* g_t1, const float* g_t2,
-                       const float* g_t3, float* scratch, int B, int ncls, hipStream_t st);
+                         int B, int H, int W, int cout, hipStream_t st);
+// kind 0: raw-t MLP (+ class embedding y); kind 1: sinusoid + 768-d MLP + additive `cond`
+int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float* cond,
+                       const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
+                       float* t3, int B, hipStream_t st);
+int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+                       const float* sin, const float* pre, const float* emb, const float* g_t1,
+                       const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
+                       hipStream_t st);
+// conv3x3 weight packs / gradient for an input tensor zero-padded from cin_real to cin channels
+int tdx_pack_conv3x3_pad(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout, int cin_real,
+                         int cin, tdx_stream_t stream);
+int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int splits, int cout, int cin,
+                                 int cin_real, tdx_stream_t stream);

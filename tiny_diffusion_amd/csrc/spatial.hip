@@ -365,31 +365,46 @@ int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, 
   return 0;
 }
 
-// --------------------------------------------------- initial_conv (1 -> 64)
-// out[p][co] = b[co] + sum_tap x[p+tap] * W[co][tap]; memory-bound (256 B written per pixel).
+// ------------------------------------- initial_conv (CIN -> COR, stored as 64 channels)
+// out[p][co] = b[co] + sum_ci sum_tap x[n][ci][p+tap] * W[co][ci][tap]; memory-bound (256 B
+// written per pixel).  x is the model input in the reference's NCHW layout
+// (1x28x28: diffusion.py:30; 4x32x32 latents: conditional_diffusion_laion.py:244); the output
+// is channels-last with a fixed stride of 64, channels >= COR written as zeros.
 #define IC_CO 64
+#define SMALLP_W 2368  // floats per block in the small-conv wgrad partial buffer (4*64*9 + 64)
+template <int CIN, int COR>
 __global__ void __launch_bounds__(256)
 initial_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                         const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
-  __shared__ float ws[9][IC_CO];
+  __shared__ float ws[CIN * 9][IC_CO];
   __shared__ float bs[IC_CO];
-  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];  // w is [co][tap]
-  if (threadIdx.x < IC_CO) bs[threadIdx.x] = bias[threadIdx.x];
+  // w is [co][ci][tap]
+  for (int i = threadIdx.x; i < CIN * 9 * IC_CO; i += 256) {
+    const int co = i / (CIN * 9), k = i % (CIN * 9);
+    ws[k][co] = co < COR ? w[i] : 0.f;
+  }
+  if (threadIdx.x < IC_CO) bs[threadIdx.x] = threadIdx.x < COR ? bias[threadIdx.x] : 0.f;
   __syncthreads();
   const int co = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
-    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
+    const float* xb = x + (int64_t)n * CIN * HW + r;
     float4 acc = make_float4(bs[co], bs[co + 1], bs[co + 2], bs[co + 3]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-        const float xv = x[p + (tap / 3 - 1) * W + (tap % 3 - 1)];
-        acc.x = fmaf(xv, ws[tap][co], acc.x);
-        acc.y = fmaf(xv, ws[tap][co + 1], acc.y);
-        acc.z = fmaf(xv, ws[tap][co + 2], acc.z);
-        acc.w = fmaf(xv, ws[tap][co + 3], acc.w);
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float xv = xb[ci * HW + (tap / 3 - 1) * W + (tap % 3 - 1)];
+          const int k = ci * 9 + tap;
+          acc.x = fmaf(xv, ws[k][co], acc.x);
+          acc.y = fmaf(xv, ws[k][co + 1], acc.y);
+          acc.z = fmaf(xv, ws[k][co + 2], acc.z);
+          acc.w = fmaf(xv, ws[k][co + 3], acc.w);
+        }
       }
     }
     *reinterpret_cast<float4*>(out + p * IC_CO + co) = acc;
@@ -397,130 +412,177 @@ initial_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w
 }
 
 int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                         int W, hipStream_t st) {
+                         int W, int cin, int cout_real, hipStream_t st) {
   const int64_t M = (int64_t)B * H * W;
-  initial_conv_fwd_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(x, w, bias, out, B, H, W);
+  const int grid = ew_grid(M, 16, 8192);
+  if (cin == 1 && cout_real == 64) initial_conv_fwd_kernel<1, 64><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W);
+  else if (cin == 4 && cout_real == 32) initial_conv_fwd_kernel<4, 32><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W);
+  else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-// dW[co][tap] = sum_p g[p][co] * x[p+tap];  db[co] = sum_p g[p][co]
-// partial[blk][640]: [co*9+tap] then [576+co]
+// dW[co][ci][tap] = sum_p g[p][co] * x[n][ci][p+tap];  db[co] = sum_p g[p][co]
+// partial[blk][SMALLP_W]: [(co*CIN+ci)*9+tap] then [COR*CIN*9 + co]
 #define ICW_PIX 256
+template <int CIN, int COR>
 __global__ void __launch_bounds__(256)
 initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                           float* __restrict__ partial, int B, int H, int W) {
-  __shared__ float red[4][10][IC_CO];
+  constexpr int NA = CIN * 9 + 1;
+  __shared__ float red[4][NA][IC_CO];
   const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
   const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
-  float acc[10];
+  float acc[NA];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int k = 0; k < NA; ++k) acc[k] = 0.f;
   for (int64_t p = p0 + pg; p < p1; p += 4) {
     const float gv = g[p * IC_CO + co];
-    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
+    const float* xb = x + (int64_t)n * CIN * HW + r;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        acc[tap] = fmaf(gv, x[p + (tap / 3 - 1) * W + (tap % 3 - 1)], acc[tap]);
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+          acc[ci * 9 + tap] = fmaf(gv, xb[ci * HW + (tap / 3 - 1) * W + (tap % 3 - 1)], acc[ci * 9 + tap]);
+      }
     }
-    acc[9] += gv;
+    acc[NA - 1] += gv;
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) red[pg][k][co] = acc[k];
+  for (int k = 0; k < NA; ++k) red[pg][k][co] = acc[k];
   __syncthreads();
-  if (pg == 0) {
+  if (pg == 0 && co < COR) {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < NA; ++k) {
       const float v = red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co];
-      partial[(size_t)blockIdx.x * 640 + (k < 9 ? co * 9 + k : 576 + co)] = v;
+      partial[(size_t)blockIdx.x * SMALLP_W + (k < NA - 1 ? co * (CIN * 9) + k : COR * CIN * 9 + co)] = v;
     }
   }
 }
 
-int tdx_initial_conv_wgrad_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, ICW_PIX); }
+int tdx_small_conv_wgrad_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, ICW_PIX); }
+int tdx_small_conv_partial_width(void) { return SMALLP_W; }
 
 int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
-                           int B, int H, int W, hipStream_t st) {
-  const int nblk = tdx_initial_conv_wgrad_blocks(B, H, W);
-  initial_conv_wgrad_kernel<<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
+                           int B, int H, int W, int cin, int cout_real, hipStream_t st) {
+  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
+  if (cin == 1 && cout_real == 64) initial_conv_wgrad_kernel<1, 64><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
+  else if (cin == 4 && cout_real == 32) initial_conv_wgrad_kernel<4, 32><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
+  else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
-  // columns [0,576) -> dw (contiguous [co][tap]), columns [576,640) -> db
-  int rc = tdx_reduce_partials(partial, dw, nblk, 640, 576, st);
+  // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
+  const int nw = cout_real * cin * 9;
+  int rc = tdx_reduce_partials(partial, dw, nblk, SMALLP_W, nw, st);
   if (rc) return rc;
-  return tdx_reduce_partials(partial + 576, db, nblk, 640, 64, st);
+  return tdx_reduce_partials(partial + nw, db, nblk, SMALLP_W, cout_real, st);
 }
 
-// ----------------------------------------------------- final_conv (64 -> 1)
-// out[p] = b + sum_tap sum_ci in[p+tap][ci] * W[ci][tap]; 16 lanes per pixel, float4 of
-// channels per lane, shuffle-reduced.
+// ------------------------------------------------------ final_conv (64 -> CO)
+// out[n][co][p] = b[co] + sum_tap sum_ci in[p+tap][ci] * W[co][ci][tap]; 16 lanes per pixel,
+// float4 of channels per lane, shuffle-reduced.  Output in the reference's NCHW layout.
+template <int CO>
 __global__ void __launch_bounds__(256)
 final_conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                       const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
-  __shared__ float ws[9][IC_CO];
-  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];  // w is [ci][tap]
+  __shared__ float ws[CO][9][IC_CO];
+  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {  // w is [co][ci][tap]
+    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
+    ws[co][r % 9][r / 9] = w[i];
+  }
   __syncthreads();
   const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
   const int64_t Mpad = (M + 15) / 16 * 16;
-  const float bv = bias[0];
+  float bv[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) bv[co] = bias[co];
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
-    float s = 0.f;
+    float s[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) s[co] = 0.f;
+    int n = 0, r = 0;
     if (p < M) {
-      const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+      n = (int)(p / HW);
+      r = (int)(p - (int64_t)n * HW);
+      const int oh = r / W, ow = r % W;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
           const float4 v = *reinterpret_cast<const float4*>(
               in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
-          s = fmaf(v.x, ws[tap][ci], s);
-          s = fmaf(v.y, ws[tap][ci + 1], s);
-          s = fmaf(v.z, ws[tap][ci + 2], s);
-          s = fmaf(v.w, ws[tap][ci + 3], s);
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            s[co] = fmaf(v.x, ws[co][tap][ci], s[co]);
+            s[co] = fmaf(v.y, ws[co][tap][ci + 1], s[co]);
+            s[co] = fmaf(v.z, ws[co][tap][ci + 2], s[co]);
+            s[co] = fmaf(v.w, ws[co][tap][ci + 3], s[co]);
+          }
         }
       }
     }
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 1, 64);
-    if ((threadIdx.x & 15) == 0 && p < M) out[p] = s + bv;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      s[co] += __shfl_xor(s[co], 8, 64);
+      s[co] += __shfl_xor(s[co], 4, 64);
+      s[co] += __shfl_xor(s[co], 2, 64);
+      s[co] += __shfl_xor(s[co], 1, 64);
+    }
+    if ((threadIdx.x & 15) == 0 && p < M) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) out[((int64_t)n * CO + co) * HW + r] = s[co] + bv[co];
+    }
   }
 }
 
 int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
-                       int W, hipStream_t st) {
+                       int W, int cout, hipStream_t st) {
   const int64_t M = (int64_t)B * H * W;
-  final_conv_fwd_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(in, w, bias, out, B, H, W);
+  const int grid = ew_grid(M, 16, 8192);
+  if (cout == 1) final_conv_fwd_kernel<1><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
+  else if (cout == 4) final_conv_fwd_kernel<4><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
+  else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-// g_in[p][ci] = sum_tap g_out[p - tapoffset] * W[ci][tap]
+// g_in[p][ci] = sum_co sum_tap g_out[n][co][p - tapoffset] * W[co][ci][tap]
+template <int CO>
 __global__ void __launch_bounds__(256)
 final_conv_dgrad_kernel(const float* __restrict__ g_out, const float* __restrict__ w,
                         float* __restrict__ g_in, int B, int H, int W) {
-  __shared__ float ws[9][IC_CO];
-  for (int i = threadIdx.x; i < 9 * IC_CO; i += 256) ws[i % 9][i / 9] = w[i];
+  __shared__ float ws[CO][9][IC_CO];
+  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {
+    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
+    ws[co][r % 9][r / 9] = w[i];
+  }
   __syncthreads();
   const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
-    const int r = (int)(p % (H * W)), ih = r / W, iw = r % W;
+    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), ih = r / W, iw = r % W;
+    const float* gb = g_out + (int64_t)n * CO * HW + r;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // output pixel (oh, ow) saw this input through tap (kh, kw) iff oh = ih - kh + 1
-      const int oh = ih - (tap / 3 - 1), ow = iw - (tap % 3 - 1);
-      if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
-        const float gv = g_out[p - (tap / 3 - 1) * W - (tap % 3 - 1)];
-        acc.x = fmaf(gv, ws[tap][ci], acc.x);
-        acc.y = fmaf(gv, ws[tap][ci + 1], acc.y);
-        acc.z = fmaf(gv, ws[tap][ci + 2], acc.z);
-        acc.w = fmaf(gv, ws[tap][ci + 3], acc.w);
+    for (int co = 0; co < CO; ++co) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // output pixel (oh, ow) saw this input through tap (kh, kw) iff oh = ih - kh + 1
+        const int oh = ih - (tap / 3 - 1), ow = iw - (tap % 3 - 1);
+        if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+          const float gv = gb[co * HW - (tap / 3 - 1) * W - (tap % 3 - 1)];
+          acc.x = fmaf(gv, ws[co][tap][ci], acc.x);
+          acc.y = fmaf(gv, ws[co][tap][ci + 1], acc.y);
+          acc.z = fmaf(gv, ws[co][tap][ci + 2], acc.z);
+          acc.w = fmaf(gv, ws[co][tap][ci + 3], acc.w);
+        }
       }
     }
     *reinterpret_cast<float4*>(g_in + p * IC_CO + ci) = acc;
@@ -528,55 +590,70 @@ final_conv_dgrad_kernel(const float* __restrict__ g_out, const float* __restrict
 }
 
 int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
-                         hipStream_t st) {
+                         int cout, hipStream_t st) {
   const int64_t M = (int64_t)B * H * W;
-  final_conv_dgrad_kernel<<<ew_grid(M, 16, 8192), 256, 0, st>>>(g_out, w, g_in, B, H, W);
+  const int grid = ew_grid(M, 16, 8192);
+  if (cout == 1) final_conv_dgrad_kernel<1><<<grid, 256, 0, st>>>(g_out, w, g_in, B, H, W);
+  else if (cout == 4) final_conv_dgrad_kernel<4><<<grid, 256, 0, st>>>(g_out, w, g_in, B, H, W);
+  else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-// dW[ci][tap] = sum_p g_out[p] * in[p+tap][ci];  db = sum_p g_out[p]
-// partial[blk][640]: [ci*9+tap], [576] = db partial (rest of the row unused)
+// dW[co][ci][tap] = sum_p g_out[n][co][p] * in[p+tap][ci];  db[co] = sum_p g_out[n][co][p]
+// partial[blk][SMALLP_W]: [(co*64+ci)*9+tap], then [CO*576 + co] = db partials
+template <int CO>
 __global__ void __launch_bounds__(256)
 final_conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ g_out,
                         float* __restrict__ partial, int B, int H, int W) {
-  __shared__ float red[4][10][IC_CO];
+  constexpr int NA = CO * 10;
+  __shared__ float red[4][NA][IC_CO];
   const int ci = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int64_t M = (int64_t)B * H * W;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
   const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
-  float acc[10];
+  float acc[NA];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int k = 0; k < NA; ++k) acc[k] = 0.f;
   for (int64_t p = p0 + pg; p < p1; p += 4) {
-    const float gv = g_out[p];
-    const int r = (int)(p % (H * W)), oh = r / W, ow = r % W;
+    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
+    float gv[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) gv[co] = g_out[((int64_t)n * CO + co) * HW + r];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        acc[tap] = fmaf(gv, in[(p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci], acc[tap]);
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        const float v = in[(p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co * 10 + tap] = fmaf(gv[co], v, acc[co * 10 + tap]);
+      }
     }
-    acc[9] += gv;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co * 10 + 9] += gv[co];
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) red[pg][k][ci] = acc[k];
+  for (int k = 0; k < NA; ++k) red[pg][k][ci] = acc[k];
   __syncthreads();
   if (pg == 0) {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < NA; ++k) {
+      const int co = k / 10, tap = k % 10;
       const float v = red[0][k][ci] + red[1][k][ci] + red[2][k][ci] + red[3][k][ci];
-      if (k < 9) partial[(size_t)blockIdx.x * 640 + ci * 9 + k] = v;
-      else if (ci == 0) partial[(size_t)blockIdx.x * 640 + 576] = v;
+      if (tap < 9) partial[(size_t)blockIdx.x * SMALLP_W + (co * IC_CO + ci) * 9 + tap] = v;
+      else if (ci == 0) partial[(size_t)blockIdx.x * SMALLP_W + CO * 576 + co] = v;
     }
   }
 }
 
 int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
-                         int B, int H, int W, hipStream_t st) {
-  const int nblk = tdx_initial_conv_wgrad_blocks(B, H, W);
-  final_conv_wgrad_kernel<<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
+                         int B, int H, int W, int cout, hipStream_t st) {
+  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
+  if (cout == 1) final_conv_wgrad_kernel<1><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
+  else if (cout == 4) final_conv_wgrad_kernel<4><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
+  else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
-  int rc = tdx_reduce_partials(partial, dw, nblk, 640, 576, st);
+  int rc = tdx_reduce_partials(partial, dw, nblk, SMALLP_W, cout * 576, st);
   if (rc) return rc;
-  return tdx_reduce_partials(partial + 576, db, nblk, 640, 1, st);
+  return tdx_reduce_partials(partial + cout * 576, db, nblk, SMALLP_W, cout, st);
 }

@@ -1,13 +1,19 @@
-// Time / class conditioning path (tiny FLOPs, latency-bound):
+// Time / class / text conditioning path (tiny FLOPs, latency-bound).
+// kind 0 (MNIST models):
 //   emb = Linear(256,256)(SiLU(Linear(1,256)(float(t)))) [+ Embedding(10,256)[y]]
 //         diffusion.py:21-25, 111-113; conditional_diffusion.py:31, 121-125
 //   t_k = time_proj_k(emb), 1x1 convs on a (B,256,1,1) map == linear 256 -> 128|256|512
 //         diffusion.py:105-107, 130-132
-// and the backward of all of it.  Kept in fp32 throughout: t is the raw integer
+// kind 1 (LAION latent model):
+//   emb = Linear(768,768)(SiLU(Linear(768,768)(sinusoid(t)))) + text_embeds
+//         conditional_diffusion_laion.py:222-232, 239-243, 306-308
+//   t_k = time_proj_k(emb): linear 768 -> 64|128|256, conditional_diffusion_laion.py:297-299
+// and the backward of all of it.  Kept in fp32 throughout: for kind 0 t is the raw integer
 // step (0..999), so pre-activations reach the hundreds.
 #include "internal.h"
 
-#define TD 256  // time_dim
+#define TD 256   // time_dim of kind 0
+#define TDL 768  // time_dim of kind 1
 
 __device__ static inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ static inline float silu_grad_f(float x) {
@@ -78,8 +84,101 @@ time_proj_kernel(const float* __restrict__ emb, const float* __restrict__ pw1,
   }
 }
 
-int tdx_time_embed_fwd(const int64_t* t, const int64_t* y, const float* const* P, float* pre,
-                       float* emb, float* t1, float* t2, float* t3, int B, hipStream_t st) {
+// ------------------------------------------------------------------ kind 1
+// sinusoid[n][j] = sin(t * f_j) for j < 384, cos(t * f_{j-384}) after;
+// f_j = exp(-ln(10000) * j / 383), every operation rounded to fp32 in the reference's order
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * TDL) return;
+  const int n = i / TDL, j = i - n * TDL, half = TDL / 2;
+  const int k = j < half ? j : j - half;
+  const float f = expf(-logf(10000.0f) * (float)k / (float)(half - 1));
+  const float a = (float)t[n] * f;
+  out[i] = j < half ? sinf(a) : cosf(a);
+}
+
+// out[n][o] = dot(W[o,:], act(in[n,:])) + b[o] (+ addend[n][o]);  rows of W are 256*R long.
+// One wave computes 16 output rows for NB samples: weight rows are read as full lines, four
+// rows in flight, and every row is reused for NB samples.  grid (ceil(B/NB), O/64).
+template <int R, int NB, bool IN_SILU>
+__global__ void __launch_bounds__(256)
+linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                   const float* __restrict__ b, const float* __restrict__ addend,
+                   float* __restrict__ out, int B, int O) {
+  constexpr int J = 256 * R;
+  const int n0 = blockIdx.x * NB, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 v[NB][R];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const int n = min(n0 + s, B - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float4 x = *reinterpret_cast<const float4*>(in + (size_t)n * J + r * 256 + lane * 4);
+      if (IN_SILU) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
+      v[s][r] = x;
+    }
+  }
+  const int o0 = blockIdx.y * 64 + wave * 16;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int o = o0 + g * 4;
+    float4 a[4][R];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        a[k][r] = *reinterpret_cast<const float4*>(w + (size_t)(o + k) * J + r * 256 + lane * 4);
+    float res = 0.f;  // lane 4*s + k keeps the result of (sample s, row k)
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          d += a[k][r].x * v[s][r].x + a[k][r].y * v[s][r].y + a[k][r].z * v[s][r].z + a[k][r].w * v[s][r].w;
+        d = wave_sum(d);
+        if (lane == 4 * s + k) res = d;
+      }
+    if (lane < 4 * NB) {
+      const int s = lane >> 2, k = lane & 3, n = n0 + s;
+      if (n < B) {
+        float e = res + b[o + k];
+        if (addend) e += addend[(size_t)n * O + o + k];
+        out[(size_t)n * O + o + k] = e;
+      }
+    }
+  }
+}
+
+static int time_embed_fwd_laion(const int64_t* t, const float* cond, const float* const* P, float* sin,
+                                float* pre, float* emb, float* t1, float* t2, float* t3, int B,
+                                hipStream_t st) {
+  constexpr int NB = 4;
+  const int gb = cdiv(B, NB);
+  sinusoid_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(t, sin, B);
+  TDX_CHECK_LAUNCH();
+  linear_rows_kernel<3, NB, false><<<dim3(gb, TDL / 64), 256, 0, st>>>(sin, P[TDX_P_TE0_W], P[TDX_P_TE0_B],
+                                                                       nullptr, pre, B, TDL);
+  TDX_CHECK_LAUNCH();
+  linear_rows_kernel<3, NB, true><<<dim3(gb, TDL / 64), 256, 0, st>>>(pre, P[TDX_P_TE2_W], P[TDX_P_TE2_B],
+                                                                      cond, emb, B, TDL);
+  TDX_CHECK_LAUNCH();
+  float* dst[3] = {t1, t2, t3};
+  const int width[3] = {64, 128, 256};
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k) {
+    linear_rows_kernel<3, NB, false><<<dim3(gb, width[k] / 64), 256, 0, st>>>(emb, P[pw[k]], P[pw[k] + 1],
+                                                                              nullptr, dst[k], B, width[k]);
+    TDX_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float* cond,
+                       const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
+                       float* t3, int B, hipStream_t st) {
+  if (kind == 1) return time_embed_fwd_laion(t, cond, P, sin, pre, emb, t1, t2, t3, B, st);
   time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
                                               P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb);
   TDX_CHECK_LAUNCH();
@@ -148,6 +247,12 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
   }
 }
 
+// g[i] *= silu'(pre[i])
+__global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] *= silu_grad_f(pre[i]);
+}
+
 // h[n][j] = silu(pre[n][j])
 __global__ void silu_kernel(const float* __restrict__ pre, float* __restrict__ h, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,10 +271,42 @@ __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int6
   de[idx] = s;
 }
 
-// scratch: g_emb (B*256) | h (B*256) | g_h (B*256)
-int tdx_time_embed_bwd(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
-                       const float* pre, const float* emb, const float* g_t1, const float* g_t2,
-                       const float* g_t3, float* scratch, int B, int ncls, hipStream_t st) {
+// the text embeddings of kind 1 come from a frozen encoder (conditional_diffusion_laion.py:216-218):
+// no gradient flows to them
+static int time_embed_bwd_laion(const float* const* P, float* const* G, const float* sin, const float* pre,
+                                const float* emb, const float* g_t1, const float* g_t2, const float* g_t3,
+                                float* scratch, int B, hipStream_t st) {
+  float* g_emb = scratch;
+  float* h = scratch + (size_t)B * TDL;
+  float* g_h = scratch + (size_t)2 * B * TDL;
+  const float* gk[3] = {g_t1, g_t2, g_t3};
+  const int ok[3] = {64, 128, 256};
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k) {
+    lin_wgrad_kernel<<<cdiv(ok[k] * TDL, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], TDL);
+    TDX_CHECK_LAUNCH();
+    lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TDL, k > 0);
+    TDX_CHECK_LAUNCH();
+  }
+  silu_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(pre, h, B * TDL);
+  TDX_CHECK_LAUNCH();
+  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TDL, TDL);
+  TDX_CHECK_LAUNCH();
+  lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TDL, TDL, 0);
+  TDX_CHECK_LAUNCH();
+  silu_bwd_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_h, pre, B * TDL);
+  TDX_CHECK_LAUNCH();
+  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_h, sin, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, TDL, TDL);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// scratch: g_emb (B*time_dim) | h (B*time_dim) | g_h (B*time_dim)
+int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+                       const float* sin, const float* pre, const float* emb, const float* g_t1,
+                       const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
+                       hipStream_t st) {
+  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * TD;
   float* g_h = scratch + (size_t)2 * B * TD;

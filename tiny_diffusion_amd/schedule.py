@@ -99,7 +99,7 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
     """Reverse process, diffusion.py:254-276.
 
     Default (``x_T is None and noises is None``): the reference's RNG consumption -
-    ``torch.randn(n,1,28,28)`` on the CPU generator moved to ``device``, then one
+    ``torch.randn(n, *model input shape)`` on the CPU generator moved to ``device``, then one
     ``torch.randn_like(x)`` per step t = T-1..1 on the device generator.
     ``noises``: mapping/sequence t -> z (recorded noise, parity tests).
     ``philox_seed``: in-kernel noise, no z tensor at all (throughput mode).
@@ -110,7 +110,8 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
     if device.type != "cuda":
         raise _lib.TdxError("sampling runs on the GPU only (no CPU fallback)")
     noise_model.eval()
-    x = (torch.randn(n_samples, 1, 28, 28) if x_T is None else x_T).to(device).float().contiguous()
+    shape = tuple(getattr(getattr(noise_model, "_arch", None), "in_shape", (1, 28, 28)))
+    x = (torch.randn(n_samples, *shape) if x_T is None else x_T).to(device).float().contiguous()
     if y is not None:
         y = y.to(device)
     T = diffusion.num_timesteps

@@ -39,11 +39,11 @@ def merge_ranges(ranges):
     return out
 
 
-def plan_buckets(offsets, cond: bool, bucket_floats: int):
+def plan_buckets(offsets, cond: bool, bucket_floats: int, time_name: str = "time_embedding"):
     """Group consecutive backward stages (unet.backward_stage_params) into buckets of at
     least ``bucket_floats`` gradient elements.  Returns [(last_stage, [(lo, hi), ...])]:
     after ``last_stage`` has run, those slices of the flat gradient are final."""
-    stages = backward_stage_params(cond)
+    stages = backward_stage_params(cond, time_name)
     buckets: List[Tuple[int, List[Tuple[int, int]]]] = []
     cur: List[Tuple[int, int]] = []
     size = 0
@@ -93,15 +93,19 @@ class BucketedAllReduce:
 class TrainStep:
     def __init__(self, model: NoiseModelBase, diffusion: ForwardProcess, lr: float = 1e-3,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None):
+                 process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None,
+                 max_grad_norm: Optional[float] = None):
         self.model = model
+        # torch.nn.utils.clip_grad_norm_(parameters, max_norm) between backward and the
+        # optimizer step (conditional_diffusion_laion.py:469); None = no clipping (MNIST scripts)
+        self.max_grad_norm = max_grad_norm
         self.diffusion = diffusion
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.pg = process_group
         self.philox_seed = philox_seed
         self._flatten()
-        self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats)
+        self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats, model._arch.time_name)
         assert self.buckets[-1][0] == self.n_stages - 1
         self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
         self.world = self.reducer.world
@@ -136,7 +140,8 @@ class TrainStep:
     # ------------------------------------------------------------------- step
     def step(self, x_0: torch.Tensor, y: Optional[torch.Tensor] = None,
              t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One optimisation step on the local shard ``x_0`` (B,1,28,28); returns the
+        """One optimisation step on the local shard ``x_0`` (B,1,28,28) - or (B,4,32,32)
+        latents with ``y`` = text embeddings (B,768) for the LAION model; returns the
         (device, not synchronised) loss tensor."""
         m, fp = self.model, self.diffusion
         B = x_0.shape[0]
@@ -159,6 +164,10 @@ class TrainStep:
             lo_stage = last_stage + 1
             self.reducer.launch(bi)          # overlaps with the next stages' kernels
         gscale = self.reducer.finish()
+        if self.max_grad_norm is not None:
+            # the flat buffer holds every gradient: one norm, one scale (stays on the device)
+            total = torch.linalg.vector_norm(self.flat_grad) * gscale
+            self.flat_grad.mul_((self.max_grad_norm / (total + 1e-6)).clamp(max=1.0))
         self.step_count += 1
         check(lib.tdx_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                 self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],

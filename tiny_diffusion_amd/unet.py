@@ -1,6 +1,7 @@
 """Host side of the MI355X noise predictor: an ``nn.Module`` with the reference's
 constructor, ``state_dict`` and ``forward(x, t[, y])`` (diffusion.py:11-162,
-conditional_diffusion.py:14-172) whose compute is libtdx.so (include/tdx.h).
+conditional_diffusion.py:14-172, conditional_diffusion_laion.py:234-332) whose compute
+is libtdx.so (include/tdx.h).
 
 The module tree below exists only to own parameters/buffers under the
 reference's names and to give the reference's default initialisation (same
@@ -21,10 +22,30 @@ from ._lib import lib, check
 
 TIME_DIM = 256
 MODE_TRAIN, MODE_EVAL_GRAD, MODE_INFER = 0, 1, 2
+KIND_MNIST, KIND_LAION = 0, 1
 
-# (name, cin, cout) of the six two-conv stages in registration order
-_ENC = (("enc1", 64, 128), ("enc2", 128, 256), ("enc3", 256, 512))
-_DEC = (("dec3", 1024, 256), ("dec2", 512, 128), ("dec1", 256, 64))
+
+class _Arch:
+    """Shape of one reference NoiseModel (mirrors SPECS[] in csrc/unet.hip)."""
+
+    def __init__(self, kind, in_shape, time_dim, time_name, x0, enc, bottleneck, dec, ceil_pool):
+        self.kind = kind
+        self.in_shape = in_shape          # (C, H, W) of x and of the prediction
+        self.time_dim = time_dim
+        self.time_name = time_name        # module name of the time MLP
+        self.x0 = x0                      # initial_conv output channels
+        self.enc, self.bottleneck, self.dec = enc, bottleneck, dec  # (name, cin, cout) stages
+        self.ceil_pool = ceil_pool
+
+
+# diffusion.py:16-107 / conditional_diffusion.py:19-113
+ARCH_MNIST = _Arch(KIND_MNIST, (1, 28, 28), 256, "time_embedding", 64,
+                   (("enc1", 64, 128), ("enc2", 128, 256), ("enc3", 256, 512)), 512,
+                   (("dec3", 1024, 256), ("dec2", 512, 128), ("dec1", 256, 64)), True)
+# conditional_diffusion_laion.py:235-301
+ARCH_LAION = _Arch(KIND_LAION, (4, 32, 32), 768, "time_mlp", 32,
+                   (("enc1", 32, 64), ("enc2", 64, 128), ("enc3", 128, 256)), 256,
+                   (("dec3", 512, 256), ("dec2", 384, 128), ("dec1", 192, 64)), False)
 # conv/BN units in the order of TDX_P_UNIT0.. (include/tdx.h)
 _UNIT_PREFIX = (
     ("enc1", 0), ("enc1", 3), ("enc2", 0), ("enc2", 3), ("enc3", 0), ("enc3", 3), ("bottleneck", 0),
@@ -36,11 +57,11 @@ def _conv_bn_relu(cin, cout):
     return [nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU()]
 
 
-def param_slot_names(cond: bool) -> List[Optional[str]]:
+def param_slot_names(cond: bool, time_name: str = "time_embedding") -> List[Optional[str]]:
     """state_dict key of every TDX_P_* slot (None where the slot is unused)."""
     names: List[Optional[str]] = [
-        "time_embedding.0.weight", "time_embedding.0.bias",
-        "time_embedding.2.weight", "time_embedding.2.bias",
+        f"{time_name}.0.weight", f"{time_name}.0.bias",
+        f"{time_name}.2.weight", f"{time_name}.2.bias",
         "class_embedding.weight" if cond else None,
         "initial_conv.weight", "initial_conv.bias",
     ]
@@ -61,7 +82,7 @@ def buffer_slot_names() -> List[str]:
     return out
 
 
-def backward_stage_params(cond: bool) -> List[List[str]]:
+def backward_stage_params(cond: bool, time_name: str = "time_embedding") -> List[List[str]]:
     """Parameters whose gradient is final after each backward stage
     (tdx_unet_backward stage order): used to bucket the gradient all-reduce."""
     stages = [["final_conv.weight", "final_conv.bias"]]
@@ -69,8 +90,8 @@ def backward_stage_params(cond: bool) -> List[List[str]]:
         stages.append([f"{stage}.{idx}.weight", f"{stage}.{idx}.bias",
                        f"{stage}.{idx + 1}.weight", f"{stage}.{idx + 1}.bias"])
     last = ["initial_conv.weight", "initial_conv.bias",
-            "time_embedding.0.weight", "time_embedding.0.bias",
-            "time_embedding.2.weight", "time_embedding.2.bias"]
+            f"{time_name}.0.weight", f"{time_name}.0.bias",
+            f"{time_name}.2.weight", f"{time_name}.2.bias"]
     if cond:
         last.append("class_embedding.weight")
     for k in (1, 2, 3):
@@ -82,12 +103,12 @@ def backward_stage_params(cond: bool) -> List[List[str]]:
 class _Plan:
     """One tdx_unet handle + workspace per (device, batch size)."""
 
-    def __init__(self, batch: int, num_classes: int, device: torch.device):
+    def __init__(self, batch: int, num_classes: int, device: torch.device, kind: int = KIND_MNIST):
         self.batch = batch
         self.device = device
         h = C.c_void_p()
         with torch.cuda.device(device):
-            check(lib.tdx_unet_create(C.byref(h), batch, num_classes), "tdx_unet_create")
+            check(lib.tdx_unet_create_ex(C.byref(h), batch, kind, num_classes), "tdx_unet_create_ex")
         self.handle = h
         self.ws_bytes = lib.tdx_unet_workspace_bytes(h, batch, MODE_TRAIN)
         if self.ws_bytes == 0:
@@ -154,34 +175,45 @@ class _UNetFunction(torch.autograd.Function):
 
 
 class NoiseModelBase(nn.Module):
-    """Shared implementation; ``NoiseModel`` in diffusion.py / conditional_diffusion.py
-    fixes ``num_classes``."""
+    """Shared implementation; ``NoiseModel`` in diffusion.py / conditional_diffusion.py /
+    conditional_diffusion_laion.py fixes ``num_classes`` and the architecture."""
 
-    def __init__(self, time_dim: int = TIME_DIM, num_classes: int = 0):
+    def __init__(self, time_dim: Optional[int] = None, num_classes: int = 0, arch: _Arch = ARCH_MNIST):
         super().__init__()
-        if time_dim != TIME_DIM:
-            raise ValueError(f"libtdx is built for time_dim={TIME_DIM} (reference default)")
+        time_dim = arch.time_dim if time_dim is None else time_dim
+        if time_dim != arch.time_dim:
+            raise ValueError(f"libtdx is built for time_dim={arch.time_dim} (reference default)")
+        if arch.kind == KIND_LAION and num_classes:
+            raise ValueError("the LAION model is conditioned on text embeddings, not class labels")
         self.time_dim = time_dim
         self.num_classes = int(num_classes)
-        # registration order == reference (diffusion.py:19-107): identical state_dict
-        # order and identical default init under the same seed
-        self.time_embedding = nn.Sequential(nn.Linear(1, time_dim), nn.SiLU(), nn.Linear(time_dim, time_dim))
+        self._arch = arch
+        # registration order == reference (diffusion.py:19-107,
+        # conditional_diffusion_laion.py:239-301): identical state_dict order and identical
+        # default init under the same seed
+        first_in = 1 if arch.kind == KIND_MNIST else time_dim
+        setattr(self, arch.time_name,
+                nn.Sequential(nn.Linear(first_in, time_dim), nn.SiLU(), nn.Linear(time_dim, time_dim)))
         if self.num_classes > 0:
             self.class_embedding = nn.Embedding(self.num_classes, time_dim)
-        self.initial_conv = nn.Conv2d(1, 64, 3, padding=1)
-        for name, cin, cout in _ENC:
+        self.initial_conv = nn.Conv2d(arch.in_shape[0], arch.x0, 3, padding=1)
+        for name, cin, cout in arch.enc:
             setattr(self, name, nn.Sequential(*_conv_bn_relu(cin, cout), *_conv_bn_relu(cout, cout)))
-        self.bottleneck = nn.Sequential(*_conv_bn_relu(512, 512))
-        for name, cin, cout in _DEC:
+        self.bottleneck = nn.Sequential(*_conv_bn_relu(arch.bottleneck, arch.bottleneck))
+        for name, cin, cout in arch.dec:
             setattr(self, name, nn.Sequential(*_conv_bn_relu(cin, cout), *_conv_bn_relu(cout, cout)))
-        self.final_conv = nn.Conv2d(64, 1, 3, padding=1)
-        self.pool = nn.MaxPool2d(2, ceil_mode=True)
-        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-        for k, c in ((1, 128), (2, 256), (3, 512)):
+        self.final_conv = nn.Conv2d(64, arch.in_shape[0], 3, padding=1)
+        if arch.kind == KIND_MNIST:
+            self.pool = nn.MaxPool2d(2, ceil_mode=True)
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        for k, (_, _, c) in zip((1, 2, 3), arch.enc):
             setattr(self, f"time_proj{k}", nn.Conv2d(time_dim, c, 1))
+        if arch.kind == KIND_LAION:  # registered after the projections in the reference
+            self.pool = nn.MaxPool2d(2)
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
 
         cond = self.num_classes > 0
-        self._slot_names = param_slot_names(cond)
+        self._slot_names = param_slot_names(cond, arch.time_name)
         self._buf_names = buffer_slot_names()
         self._param_order = [n for n in self._slot_names if n is not None]
         self._plans = {}
@@ -200,7 +232,7 @@ class NoiseModelBase(nn.Module):
         key = (device.index if device.index is not None else torch.cuda.current_device(), batch)
         p = self._plans.get(key)
         if p is None:
-            p = _Plan(batch, self.num_classes, device)
+            p = _Plan(batch, self.num_classes, device, self._arch.kind)
             self._plans[key] = p
         return p
 
@@ -241,10 +273,17 @@ class NoiseModelBase(nn.Module):
             raise _lib.TdxError(
                 "tiny_diffusion_amd runs on MI355X only: got a CPU tensor and there is no "
                 "CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
-        if x.dim() != 4 or x.shape[1:] != (1, 28, 28):
-            raise ValueError(f"x must be (B,1,28,28), got {tuple(x.shape)}")
+        shp = self._arch.in_shape
+        if x.dim() != 4 or tuple(x.shape[1:]) != shp:
+            raise ValueError(f"x must be (B,{shp[0]},{shp[1]},{shp[2]}), got {tuple(x.shape)}")
         if t.shape != (x.shape[0],):
             raise ValueError("t must have shape (B,)")
+        if self._arch.kind == KIND_LAION:
+            if y is None or tuple(y.shape) != (x.shape[0], self.time_dim):
+                raise ValueError(f"text_embeds must have shape (B,{self.time_dim})")
+            if not y.is_cuda:
+                raise _lib.TdxError("text_embeds must be a CUDA tensor")
+            return
         if (self.num_classes > 0) != (y is not None):
             raise ValueError("class labels y are required exactly for the conditional model")
         if y is not None and y.shape != (x.shape[0],):
@@ -259,8 +298,9 @@ class NoiseModelBase(nn.Module):
         bptr, btens = self._buffer_ptrs()
         x = x.contiguous().float()
         t = t.contiguous().to(torch.int64)
-        y = None if y is None else y.contiguous().to(torch.int64)
-        out = torch.empty((B, 1, 28, 28), dtype=torch.float32, device=x.device)
+        if y is not None:
+            y = y.contiguous().float() if self._arch.kind == KIND_LAION else y.contiguous().to(torch.int64)
+        out = torch.empty((B,) + tuple(self._arch.in_shape), dtype=torch.float32, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream
         if mode == MODE_INFER:
             # running statistics are updated by kernels (no torch version bump): _buf_epoch
