@@ -147,6 +147,55 @@ def sample_latency(model, diffusion, n: int):
     return dt
 
 
+# forward FLOPs per sample of the LAION UNet's 3x3 convs (conditional_diffusion_laion.py:244-296):
+# (cin, cout, hw) per conv incl. initial/final
+_LAION_CONVS = [(4, 32, 32), (32, 64, 32), (64, 64, 32), (64, 128, 16), (128, 128, 16), (128, 256, 8),
+                (256, 256, 8), (256, 256, 4), (512, 256, 8), (256, 256, 8), (384, 128, 16), (128, 128, 16),
+                (192, 64, 32), (64, 64, 32), (64, 4, 32)]
+LAION_FWD_FLOP = sum(2 * 9 * ci * co * hw * hw for ci, co, hw in _LAION_CONVS)
+
+
+def laion_extras(steps: int = 20, warmup: int = 5):
+    """SURVEY.md 8(f) f3 (BASELINE.json configs[4] shape): training step of the LAION-shaped
+    latent UNet (q_sample + fwd + MSE + bwd + clip_grad_norm(10) + Adam, cosine LR) at the
+    reference's batch 8 and at 256, and the 1000-step reverse chain for its 4 prompts."""
+    from tiny_diffusion_amd.conditional_diffusion_laion import ForwardProcess, NoiseModel, sample
+    from tiny_diffusion_amd.train import TrainStep
+
+    out = {"fwd_gflop_per_sample": round(LAION_FWD_FLOP / 1e9, 3)}
+    fp = ForwardProcess()
+    for B in (8, 256):
+        torch.manual_seed(0)
+        model = NoiseModel(time_dim=768).cuda().train()
+        ts = TrainStep(model, fp, lr=1e-4, philox_seed=99, max_grad_norm=10.0, cosine_T_max=1000,
+                       cosine_eta_min=1e-6)
+        x0 = torch.randn(B, 4, 32, 32, device="cuda") * 0.8
+        cond = torch.randn(B, 768, device="cuda")
+        for _ in range(warmup):
+            ts.step(x0, cond)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = ts.step(x0, cond)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lv = loss.item()
+        if not (lv == lv) or lv > 1e3:
+            raise SystemExit(f"LAION training diverged in the benchmark: loss {lv}")
+        out[f"train_B{B}"] = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                              "tflops": round(B * steps / dt * 3 * LAION_FWD_FLOP / 1e12, 2)}
+        if B == 8:
+            model.eval()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x = sample(model, fp, "cuda", text_embeds=cond[:4], use_graph=True, philox_seed=7)
+            torch.cuda.synchronize()
+            assert torch.isfinite(x).all()
+            out["sample_n4_s_per_1000_steps"] = round(time.perf_counter() - t0, 3)
+        del ts, model
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +295,7 @@ def main():
             res["sample"] = {"unit": "s per 1000-step chain (HIP-graph replay, in-kernel Philox noise)",
                              "n16": round(sample_latency(model, fp, 16), 3),
                              "n64": round(sample_latency(model, fp, 64), 3)}
+            res["laion_unet"] = laion_extras()
         print(json.dumps(res))
     if use_dist:
         torch.distributed.destroy_process_group()

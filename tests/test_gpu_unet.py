@@ -314,3 +314,41 @@ def test_sample_default_rng_consumption():
     assert torch.equal(a, b) and a.shape == (4, 1, 28, 28) and torch.isfinite(a).all()
     c = sample(m, fp, "cuda", n_samples=4, philox_seed=3)
     assert torch.isfinite(c).all()
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_train_step_matches_module_plus_torch_adam(cond):
+    """TrainStep (q_sample + forward + mse + staged backward + fused flat Adam, the pipeline
+    bench.py times) against the same step written like the reference loop with the module,
+    F.mse_loss, loss.backward() and torch.optim.Adam (diffusion.py:216-236), two steps."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+    from tiny_diffusion_amd.train import TrainStep
+
+    fp = ForwardProcess()
+    m, ref = build(cond, 3), build(cond, 3)
+    m.train(); ref.train()
+    ts = TrainStep(m, fp, lr=1e-3)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(11)
+    for step in range(2):
+        x0 = (torch.rand(6, 1, 28, 28, generator=g) * 2 - 1).cuda()
+        noise = torch.randn(6, 1, 28, 28, generator=g).cuda()
+        t = torch.randint(0, 1000, (6,), generator=g).cuda()
+        y = torch.randint(0, 10, (6,), generator=g).cuda() if cond else None
+        loss = ts.step(x0, y, t=t, noise=noise)
+        x_t, _ = fp.q_sample("cuda", x0, t, noise=noise)
+        l2 = F.mse_loss(ref(x_t, t, y) if cond else ref(x_t, t), noise)
+        opt.zero_grad()
+        l2.backward()
+        opt.step()
+        assert abs(float(loss) - l2.item()) <= 2e-6 * abs(l2.item()), step
+        if step == 0:
+            # first Adam step: each weight moves by ~lr*sign(g) unless |g| ~ eps (1e-8)
+            for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+                if is_pre_bn_bias(k):
+                    continue
+                diff = (a - b).abs()
+                assert diff.max().item() <= 2.1e-3, k
+                assert (diff > 1e-5).float().mean().item() <= 2e-3, (k, (diff > 1e-5).float().mean().item())
+    for (k, a), (_, b) in zip(m.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), k

@@ -89,3 +89,44 @@ def test_default_init_is_the_reference_init(golden_dir):
         pytest.skip("golden file predates the init hash")
     torch.manual_seed(0)
     assert state_dict_sha256(NoiseModel().state_dict()) == want["init uncond_seed0"]
+
+
+def test_laion_module_layout_and_stage_buckets():
+    """conditional_diffusion_laion.NoiseModel: reference state_dict order/shapes, slot and
+    backward-stage tables cover every parameter (CPU: no compute)."""
+    from oracle.weights import key_shapes_laion, make_state_dict_laion
+    from tiny_diffusion_amd import _lib
+    from tiny_diffusion_amd.conditional_diffusion_laion import NoiseModel, get_timestep_embedding
+    from tiny_diffusion_amd.unet import backward_stage_params, param_slot_names
+
+    m = NoiseModel(time_dim=768)
+    sd = m.state_dict()
+    assert [k for k, _, _ in key_shapes_laion()] == list(sd.keys())
+    m.load_state_dict(make_state_dict_laion(0), strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 5_793_124
+    names = [n for n, _ in m.named_parameters()]
+    slots = param_slot_names(False, "time_mlp")
+    assert sorted(s for s in slots if s) == sorted(names) and len(slots) == 67 and slots[4] is None
+    staged = [n for st in backward_stage_params(False, "time_mlp") for n in st]
+    assert sorted(staged) == sorted(names)
+    with pytest.raises(_lib.TdxError):
+        m(torch.zeros(2, 4, 32, 32), torch.zeros(2, dtype=torch.long), torch.zeros(2, 768))
+    from oracle import ref_laion as RL
+    t = torch.tensor([0, 7, 999])
+    assert torch.equal(get_timestep_embedding(t, 768), RL.timestep_embedding(t, 768))
+
+
+def test_cosine_schedule_matches_torch():
+    """cosine_annealing_lr == CosineAnnealingLR stepped per batch, past T_max too
+    (conditional_diffusion_laion.py:436-438, 473)."""
+    from tiny_diffusion_amd.train import cosine_annealing_lr
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=7, eta_min=1e-6)
+    for step in range(1, 30):
+        opt.step()
+        sched.step()
+        want = opt.param_groups[0]["lr"]
+        got = cosine_annealing_lr(step, 1e-4, 7, 1e-6)
+        assert abs(got - want) <= 1e-9 * max(abs(want), 1e-6) + 1e-12, (step, got, want)

@@ -19,6 +19,7 @@ statistics stay rank-local (DistributedDataParallel semantics).
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import List, Optional, Tuple
 
@@ -90,12 +91,23 @@ class BucketedAllReduce:
         return 1.0 / self.world
 
 
+def cosine_annealing_lr(step: int, base_lr: float, T_max: int, eta_min: float = 0.0) -> float:
+    """Learning rate after ``step`` calls of ``CosineAnnealingLR(T_max, eta_min).step()``
+    (conditional_diffusion_laion.py:436-438, 473: stepped once per BATCH although T_max counts
+    epochs, so the rate swings between base_lr and eta_min with period 2*T_max batches -
+    reproduced as written; the closed form equals torch's chained recursion)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * step / T_max)) / 2.0
+
+
 class TrainStep:
     def __init__(self, model: NoiseModelBase, diffusion: ForwardProcess, lr: float = 1e-3,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None,
-                 max_grad_norm: Optional[float] = None):
+                 max_grad_norm: Optional[float] = None, cosine_T_max: Optional[int] = None,
+                 cosine_eta_min: float = 0.0):
         self.model = model
+        # CosineAnnealingLR(optimizer, T_max, eta_min) stepped after every optimizer step
+        self.base_lr, self.cosine_T_max, self.cosine_eta_min = lr, cosine_T_max, cosine_eta_min
         # torch.nn.utils.clip_grad_norm_(parameters, max_norm) between backward and the
         # optimizer step (conditional_diffusion_laion.py:469); None = no clipping (MNIST scripts)
         self.max_grad_norm = max_grad_norm
@@ -173,6 +185,8 @@ class TrainStep:
                                 self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
                                 self.betas[1], self.eps, self.step_count, gscale, st),
               "tdx_adam_step")                                                 # diffusion.py:236
+        if self.cosine_T_max is not None:
+            self.lr = cosine_annealing_lr(self.step_count, self.base_lr, self.cosine_T_max, self.cosine_eta_min)
         return self.loss
 
     def broadcast_parameters(self, src: int = 0):
