@@ -196,3 +196,106 @@ def make_state_dict_laion(seed: int = 0):
             raise AssertionError(kind)
         sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return sd
+
+
+# --------------------------------------------------------------------------
+# latent_diffusion.py NoiseModel: MLP on 20-d VAE latents,
+# and the MLP VAE of vae.py:37-62
+# --------------------------------------------------------------------------
+# (name, in, mid/out) of the two-Linear stages, latent_diffusion.py:37-97
+_LATENT_STAGES = [
+    ("enc1", 512, 512, 256),
+    ("enc2", 256, 256, 128),
+    ("enc3", 128, 128, 64),
+    ("dec3", 128, 128, 128),
+    ("dec2", 256, 256, 256),
+    ("dec1", 512, 512, 512),
+]
+
+
+def key_shapes_latent(num_classes: int = 10, time_dim: int = TIME_DIM, latent_dim: int = 20):
+    """Ordered (key, shape, kind) == state_dict() of latent_diffusion.NoiseModel
+    (latent_diffusion.py:16-105)."""
+    out = []
+
+    def lin(name, cin, cout):
+        out.append((f"{name}.weight", (cout, cin), "lin_w"))
+        out.append((f"{name}.bias", (cout,), "bias"))
+
+    def bn(name, c):
+        out.append((f"{name}.weight", (c,), "bn_w"))
+        out.append((f"{name}.bias", (c,), "bn_b"))
+        out.append((f"{name}.running_mean", (c,), "bn_rm"))
+        out.append((f"{name}.running_var", (c,), "bn_rv"))
+        out.append((f"{name}.num_batches_tracked", (), "bn_nbt"))
+
+    def stage(name, cin, mid, cout):
+        lin(f"{name}.0", cin, mid)
+        bn(f"{name}.1", mid)
+        lin(f"{name}.3", mid, cout)
+        bn(f"{name}.4", cout)
+
+    lin("time_embedding.0", 1, time_dim)
+    lin("time_embedding.2", time_dim, time_dim)
+    out.append(("class_embedding.weight", (num_classes, time_dim), "emb"))
+    lin("initial_fc", latent_dim, 512)
+    for s in _LATENT_STAGES[:3]:
+        stage(*s)
+    lin("bottleneck.0", 64, 64)
+    bn("bottleneck.1", 64)
+    for s in _LATENT_STAGES[3:]:
+        stage(*s)
+    lin("final_fc", 512, latent_dim)
+    lin("time_proj1", time_dim, 64)
+    lin("time_proj2", time_dim, 128)
+    lin("time_proj3", time_dim, 256)
+    return out
+
+
+def _fill(rs, key_shape_kinds, time_first=None):
+    sd = OrderedDict()
+    for key, shape, kind in key_shape_kinds:
+        if kind in ("conv_w", "lin_w"):
+            fan_in = int(np.prod(shape[1:]))
+            a = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+            if key == time_first:
+                a = a / 100.0  # raw t in [0, 1000) feeds this layer (latent_diffusion.py:108-109)
+        elif kind == "bias":
+            a = rs.standard_normal(shape) * 0.01
+        elif kind == "bn_w":
+            a = 1.0 + rs.standard_normal(shape) * 0.1
+        elif kind == "bn_b":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rm":
+            a = rs.standard_normal(shape) * 0.1
+        elif kind == "bn_rv":
+            a = 1.0 + np.abs(rs.standard_normal(shape) * 0.1)
+        elif kind == "bn_nbt":
+            sd[key] = torch.tensor(1, dtype=torch.int64)
+            continue
+        elif kind == "emb":
+            a = rs.standard_normal(shape)
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return sd
+
+
+def make_state_dict_latent(seed: int = 0):
+    """Seeded reference-format state_dict of latent_diffusion.NoiseModel."""
+    return _fill(np.random.RandomState(seed), key_shapes_latent(), "time_embedding.0.weight")
+
+
+def key_shapes_vae(input_dim: int = 784, hidden_dim: int = 400, latent_dim: int = 20):
+    """state_dict() of vae.VAE (vae.py:42-49)."""
+    out = []
+    for name, cin, cout in (("fc1", input_dim, hidden_dim), ("fc21", hidden_dim, latent_dim),
+                            ("fc22", hidden_dim, latent_dim), ("fc3", latent_dim, hidden_dim),
+                            ("fc4", hidden_dim, input_dim)):
+        out.append((f"{name}.weight", (cout, cin), "lin_w"))
+        out.append((f"{name}.bias", (cout,), "bias"))
+    return out
+
+
+def make_state_dict_vae(seed: int = 0):
+    return _fill(np.random.RandomState(seed), key_shapes_vae())

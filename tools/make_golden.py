@@ -312,7 +312,116 @@ def laion_fixtures(mod):
     print("laion_B8 loss train/eval", d["loss_train"], d["loss_eval"])
 
 
+def load_reference_latent():
+    """latent_diffusion.py imports vae.py, whose module body builds MNIST datasets
+    (``download=True``), data loaders, a model, an optimizer and ``os.makedirs("checkpoints")``
+    (vae.py:79-101).  None of that is on the path: the torchvision stub hands it a 4-image
+    in-memory dataset (nothing is fetched) and the import runs inside a scratch directory, so
+    the only things taken from the two modules are the classes ``VAE``/``VAEConfig`` and
+    ``NoiseModel``/``ForwardProcess``."""
+    import tempfile
+
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", Compose=lambda fs: None, ToTensor=lambda: None,
+                          Normalize=lambda *a: None)
+    tiny = torch.utils.data.TensorDataset(torch.zeros(4, 1, 28, 28), torch.zeros(4, dtype=torch.long))
+    tv.datasets = _stub("torchvision.datasets", MNIST=lambda **kw: tiny)
+    tv.utils = _stub("torchvision.utils")
+    _stub("wandb")
+    cwd = os.getcwd()
+    rng_state = torch.get_rng_state()
+    with tempfile.TemporaryDirectory() as scratch:
+        os.chdir(scratch)
+        try:
+            spec = importlib.util.spec_from_file_location("vae", os.path.join(REF, "vae.py"))
+            vae_mod = importlib.util.module_from_spec(spec)
+            sys.modules["vae"] = vae_mod          # `from vae import VAE, VAEConfig` (latent_diffusion.py:13)
+            spec.loader.exec_module(vae_mod)
+            spec = importlib.util.spec_from_file_location("ref_latent_diffusion",
+                                                          os.path.join(REF, "latent_diffusion.py"))
+            lat = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(lat)
+        finally:
+            os.chdir(cwd)
+    torch.set_rng_state(rng_state)   # vae.py seeds the global generator (vae.py:33)
+    return lat, vae_mod
+
+
+def latent_fixtures():
+    """latent_diffusion.py NoiseModel + vae.py VAE on synthetic inputs (SURVEY.md 8(d):
+    z_0 = randn(B,20); no trained VAE checkpoint exists in the container)."""
+    from oracle.weights import make_state_dict_latent, make_state_dict_vae
+
+    lat, vae_mod = load_reference_latent()
+    sd, vsd = make_state_dict_latent(0), make_state_dict_vae(0)
+    rs = np.random.RandomState(777)
+    B = 32
+    x_img = (rs.rand(B, 784) * 2 - 1).astype(np.float32)
+    eps_vae = rs.standard_normal((B, 20)).astype(np.float32)
+    noise = rs.standard_normal((B, 20)).astype(np.float32)
+    t = rs.randint(0, 1000, size=(B,)).astype(np.int64); t[0], t[1] = 0, 999
+    y = rs.randint(0, 10, size=(B,)).astype(np.int64)
+    cfg = vae_mod.VAEConfig()
+    vae = vae_mod.VAE(cfg); vae.load_state_dict(vsd, strict=True); vae.eval()
+    with torch.no_grad():
+        mu, logvar = vae.encode(torch.from_numpy(x_img))              # latent_diffusion.py:205
+        z0 = mu + torch.from_numpy(eps_vae) * torch.exp(0.5 * logvar)  # vae.py:55-58 with recorded eps
+        dec = vae.decode(z0)
+    fp = lat.ForwardProcess()
+    tt, nt, yt = torch.from_numpy(t), torch.from_numpy(noise), torch.from_numpy(y)
+    z_t = torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1) * z0 + torch.sqrt(1 - fp.alphas_cumprod[tt]).view(-1, 1) * nt
+    d = dict(x_img=x_img, eps_vae=eps_vae, mu=mu.numpy(), logvar=logvar.numpy(), z0=z0.numpy(), dec=dec.numpy(),
+             z_t=z_t.numpy(), noise=noise, t=t, y=y)
+    for mode in ("train", "eval"):
+        model = lat.NoiseModel(); model.load_state_dict(sd, strict=True); model.train(mode == "train")
+        with torch.no_grad():
+            eps = model(z_t, tt, yt)
+        d[f"eps_{mode}"] = eps.numpy()
+        d[f"loss_{mode}"] = np.float64(F.mse_loss(eps, nt).item())
+        if mode == "train":
+            d.update({"buf__" + k: v for k, v in bn_buffers(model).items()})
+    model = lat.NoiseModel(); model.load_state_dict(sd, strict=True); model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss = F.mse_loss(model(z_t, tt, yt), nt); opt.zero_grad(); loss.backward()
+    for k, p in model.named_parameters():
+        g = p.grad.detach().contiguous().view(-1); kk = k.replace(".", "__")
+        d[f"gnorm__{kk}"] = np.float64(g.double().norm().item())
+        d[f"ghead__{kk}"] = g[:256].numpy().copy()
+    opt.step()
+    for k, p in model.named_parameters():
+        d["adam_head__" + k.replace(".", "__")] = p.detach().contiguous().view(-1)[:64].numpy().copy()
+    # reverse chain + decode (latent_diffusion.py:321-346), T = 10, recorded noise
+    T, n = 10, 4
+    fpT = lat.ForwardProcess(num_timesteps=T)
+    model = lat.NoiseModel(); model.load_state_dict(sd, strict=True); model.eval()
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(n, 20, generator=g); z_T = z.clone()
+    zs = np.zeros((T, n, 20), np.float32)
+    ys = yt[:n]
+    with torch.no_grad():
+        for step in reversed(range(T)):
+            eps = model(z, torch.full((n,), step, dtype=torch.long), ys)
+            zz = torch.randn(z.shape, generator=g) if step > 0 else torch.zeros_like(z)
+            zs[step] = zz.numpy()
+            alpha, ac, beta = fpT.alphas[step], fpT.alphas_cumprod[step], fpT.betas[step]
+            z = (1 / torch.sqrt(alpha)) * (z - ((1 - alpha) / torch.sqrt(1 - ac)) * eps) + torch.sqrt(beta) * zz
+        img = vae.decode(z).view(-1, 1, 28, 28)
+    d.update(chain_z_T=z_T.numpy(), chain_zs=zs, chain_final=z.numpy(), chain_img=img.numpy(), chain_T=T)
+    np.savez_compressed(os.path.join(OUT, "latent_B32.npz"), **d)
+    with open(os.path.join(OUT, "weights.sha256"), "a") as f:
+        f.write(f"latent seed0 {state_dict_sha256(sd)}\n")
+        f.write(f"vae seed0 {state_dict_sha256(vsd)}\n")
+        torch.manual_seed(0)
+        f.write(f"init latent_seed0 {state_dict_sha256(lat.NoiseModel().state_dict())}\n")
+        torch.manual_seed(0)
+        f.write(f"init vae_seed0 {state_dict_sha256(vae_mod.VAE(cfg).state_dict())}\n")
+    print("latent_B32 loss train/eval", d["loss_train"], d["loss_eval"])
+
+
 def main():
+    if "--latent-only" in sys.argv:
+        latent_fixtures()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     unc = load_reference("diffusion.py")
@@ -338,6 +447,7 @@ def main():
     sample_fixture(con, True, 20, 4, keep=[19, 10, 1, 0])
     sample_fixture(unc, False, 1000, 4, keep=[999, 750, 500, 250, 1, 0])
     laion_fixtures(load_reference("conditional_diffusion_laion.py"))
+    latent_fixtures()
 
 
 if __name__ == "__main__":
