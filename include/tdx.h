@@ -213,6 +213,29 @@ enum {
 #define TDX_MODE_EVAL_GRAD 1  /* running statistics, activations saved for backward */
 #define TDX_MODE_INFER 2      /* running statistics, fused conv+BN+ReLU, nothing saved */
 
+/* ---- Linear layers and the MLP VAE (latent_diffusion.py / vae.py) -------
+ * out[M,N] (row stride ldo) = act(x[M,K] (row stride ldx) . w[N,K]^T + bias);  nn.Linear layout.
+ * act: 0 none, 1 ReLU, 2 sigmoid. */
+int tdx_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                   int M, int N, int K, int act, tdx_stream_t stream);
+/* Backward of y = x w^T + b given gy[M,N]: dw[N,K] = gy^T x, db[N] = column sums of gy,
+ * gx[M,K] = gy w.  Any of dw / db / gx may be NULL (skipped). */
+int tdx_linear_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* w, float* gx,
+                   int ldgx, float* dw, float* db, int M, int N, int K, tdx_stream_t stream);
+/* VAE.encode (vae.py:51-53): params = {fc1.w, fc1.b, fc21.w, fc21.b, fc22.w, fc22.b};
+ * x (B,input_dim) -> mu, logvar (B,latent_dim).  workspace: tdx_vae_workspace_floats() floats. */
+size_t tdx_vae_workspace_floats(int batch, int hidden_dim);
+int tdx_vae_encode(const float* x, const void* const* params, float* mu, float* logvar,
+                   float* workspace, int batch, int input_dim, int hidden_dim, int latent_dim,
+                   tdx_stream_t stream);
+/* VAE.reparameterize (vae.py:55-58) with caller-supplied eps: z = mu + eps * exp(0.5 logvar). */
+int tdx_vae_reparameterize(const float* mu, const float* logvar, const float* eps, float* z,
+                           int64_t n, tdx_stream_t stream);
+/* VAE.decode (vae.py:60-62): params = {fc3.w, fc3.b, fc4.w, fc4.b}; z (B,latent_dim) ->
+ * sigmoid output (B,input_dim). */
+int tdx_vae_decode(const float* z, const void* const* params, float* out, float* workspace,
+                   int batch, int input_dim, int hidden_dim, int latent_dim, tdx_stream_t stream);
+
 typedef struct tdx_unet tdx_unet;
 
 /* num_classes == 0: unconditional (diffusion.py); > 0: class-conditional. */
@@ -221,8 +244,12 @@ int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes);
  * kind TDX_UNET_LAION: NoiseModel of conditional_diffusion_laion.py:234-332 - 4x32x32 latents,
  *   widths 32..256, sinusoidal timestep embedding + Linear(768,768) MLP, additive 768-d text
  *   conditioning (num_classes must be 0).  Same parameter/buffer slot numbering; slot
- *   TDX_P_CLASS_EMB is unused, TDX_P_TE0_W is (768,768). */
-enum { TDX_UNET_MNIST = 0, TDX_UNET_LAION = 1 };
+ *   TDX_P_CLASS_EMB is unused, TDX_P_TE0_W is (768,768).
+ * kind TDX_UNET_LATENT_MLP: NoiseModel of latent_diffusion.py:16-128 - MLP on (B,20) VAE latents,
+ *   13 Linear+BatchNorm1d+ReLU units 512..64..512, class-conditional (num_classes > 0); the same
+ *   slot numbering with Linear weights (out,in) in the conv-weight slots, initial_fc / final_fc in
+ *   TDX_P_INIT_* / TDX_P_FINAL_*; x and out are (B,20). */
+enum { TDX_UNET_MNIST = 0, TDX_UNET_LAION = 1, TDX_UNET_LATENT_MLP = 2 };
 int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes);
 int tdx_unet_destroy(tdx_unet* u);
 size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode);
@@ -232,6 +259,7 @@ size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode);
  *   params: TDX_P_COUNT device pointers (reference layout); buffers: TDX_B_COUNT.
  *   kind MNIST: x (B,1,28,28) fp32; t (B,) int64; cond = y (B,) int64 labels or NULL; out (B,1,28,28).
  *   kind LAION: x (B,4,32,32) fp32; t (B,) int64; cond = text_embeds (B,768) fp32; out (B,4,32,32).
+ *   kind LATENT_MLP: x (B,20) fp32; t (B,) int64; cond = y (B,) int64 labels; out (B,20).
  * In TRAIN mode the BN running buffers are updated in place. */
 int tdx_unet_forward(tdx_unet* u, const void* const* params, void* const* buffers,
                      const float* x, const int64_t* t, const void* cond, float* out,

@@ -85,6 +85,13 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_bilinear_ac_bwd": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _ptr]),
+    "tdx_linear_fwd": (C.c_int, [_ptr, C.c_int, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_linear_bwd": (C.c_int, [_ptr, C.c_int, _ptr, C.c_int, _ptr, _ptr, C.c_int, _ptr, _ptr, C.c_int, C.c_int,
+                                 C.c_int, _ptr]),
+    "tdx_vae_workspace_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "tdx_vae_encode": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_vae_reparameterize": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr]),
+    "tdx_vae_decode": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_unet_create": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int]),
     "tdx_unet_create_ex": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int]),
     "tdx_unet_destroy": (C.c_int, [_ptr]),

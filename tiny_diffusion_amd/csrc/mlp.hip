@@ -1,0 +1,545 @@
+// Latent-space DDPM: the MLP noise predictor of latent_diffusion.py:16-128,
+// its autograd backward, and the MLP VAE of vae.py:37-62.
+//
+// 2.8 MFLOP per sample forward: nothing here is throughput-bound, the cost is the length of the
+// dependent launch chain.  So the building blocks are few and generic:
+//   * one fp32 register-tiled GEMM (64x64x16, 4x4 per thread) with operand-layout template
+//     flags, serving Linear forward (X W^T), input gradient (gY W) and weight gradient (gY^T X),
+//     with a fused epilogue: + bias, eval-mode BatchNorm folded to scale/shift, ReLU / sigmoid,
+//     + per-row addend (the time signal), strided output (writes straight into the concat
+//     buffers, latent_diffusion.py:124-126);
+//   * BatchNorm1d (train) forward / backward as ONE kernel each: a workgroup owns 32 features
+//     for ALL rows, so batch statistics and the two backward reductions never leave the block.
+#include "internal.h"
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+
+namespace {
+
+constexpr int GT = 64;   // tile edge
+constexpr int GK = 16;   // k-tile
+constexpr float BN1_EPS = 1e-5f;
+constexpr float BN1_MOMENTUM = 0.1f;
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+  const float* bias;     // [N] or null
+  const float* scale;    // [N] or null: y = (acc + bias) * scale + shift
+  const float* shift;
+  const float* addrow;   // [M x N] (ldr) added after the activation, or null
+  int ldr;
+  int act;               // 0 none, 1 relu, 2 sigmoid
+  int accumulate;        // C += result
+};
+
+// A_KC: A(m,k) = A[m*lda + k] else A[k*lda + m];  B_KC: B(k,n) = B[n*ldb + k] else B[k*ldb + n]
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[GK][GT + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[GK][GT + 4];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < g.K; k0 += GK) {
+    if (A_KC) {
+      const int r = t >> 2, c4 = (t & 3) * 4, m = m0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + c4 + i;
+        As[c4 + i][r] = (m < g.M && k < g.K) ? g.A[(size_t)m * g.lda + k] : 0.f;
+      }
+    } else {
+      const int kk = t >> 4, c4 = (t & 15) * 4, k = k0 + kk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + c4 + i;
+        As[kk][c4 + i] = (m < g.M && k < g.K) ? g.A[(size_t)k * g.lda + m] : 0.f;
+      }
+    }
+    if (B_KC) {
+      const int r = t >> 2, c4 = (t & 3) * 4, n = n0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + c4 + i;
+        Bs[c4 + i][r] = (n < g.N && k < g.K) ? g.B[(size_t)n * g.ldb + k] : 0.f;
+      }
+    } else {
+      const int kk = t >> 4, c4 = (t & 15) * 4, k = k0 + kk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + c4 + i;
+        Bs[kk][c4 + i] = (n < g.N && k < g.K) ? g.B[(size_t)k * g.ldb + n] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= g.N) continue;
+      float v = acc[i][j];
+      if (g.bias) v += g.bias[n];
+      if (g.scale) v = fmaf(v, g.scale[n], g.shift[n]);
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+      if (g.addrow) v += g.addrow[(size_t)m * g.ldr + n];
+      float* dst = g.C + (size_t)m * g.ldc + n;
+      *dst = g.accumulate ? *dst + v : v;
+    }
+  }
+}
+
+int launch_gemm(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return TDX_E_BADARG;
+  dim3 grid(cdiv(g.N, GT), cdiv(g.M, GT));
+  if (a_kc && b_kc) gemm_kernel<true, true><<<grid, 256, 0, st>>>(g);
+  else if (a_kc) gemm_kernel<true, false><<<grid, 256, 0, st>>>(g);
+  else if (b_kc) gemm_kernel<false, true><<<grid, 256, 0, st>>>(g);
+  else gemm_kernel<false, false><<<grid, 256, 0, st>>>(g);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[M x N] (ldo) = epilogue(X[M x K] (ldx) . W[N x K]^T)
+int linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int M,
+               int N, int K, int act, const float* scale, const float* shift, const float* addrow, int ldr,
+               hipStream_t st) {
+  GemmArgs g{x, w, out, M, N, K, ldx, K, ldo, bias, scale, shift, addrow, ldr, act, 0};
+  return launch_gemm(g, true, true, st);
+}
+// gx[M x K] (ldgx) (+)= gy[M x N] (ldgy) . W[N x K]
+int linear_dgrad(const float* gy, int ldgy, const float* w, float* gx, int ldgx, int M, int N, int K,
+                 int accumulate, hipStream_t st) {
+  GemmArgs g{gy, w, gx, M, K, N, ldgy, K, ldgx, nullptr, nullptr, nullptr, nullptr, 0, 0, accumulate};
+  return launch_gemm(g, true, false, st);
+}
+// dw[N x K] = gy[M x N]^T (ldgy) . x[M x K] (ldx)
+int linear_wgrad(const float* gy, int ldgy, const float* x, int ldx, float* dw, int M, int N, int K,
+                 hipStream_t st) {
+  GemmArgs g{gy, x, dw, N, K, M, ldgy, ldx, K, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  return launch_gemm(g, false, false, st);
+}
+
+// out[n] = sum_m g[m*ld + n]   (bias gradient); block = 32 columns x 8 row slices
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ g, int ld, int M, int N, float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, n = blockIdx.x * 32 + cl;
+  float s = 0.f;
+  if (n < N)
+    for (int m = sl; m < M; m += 8) s += g[(size_t)m * ld + n];
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][cl];
+    out[n] = v;
+  }
+}
+
+int colsum(const float* g, int ld, int M, int N, float* out, hipStream_t st) {
+  colsum_kernel<<<cdiv(N, 32), 256, 0, st>>>(g, ld, M, N, out);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------- BatchNorm1d + ReLU
+// block = 32 features x 8 interleaved row slices; the block sees every row of its features.
+__device__ inline float block_colsum(float v, float (*red)[32], int sl, int cl) {
+  __syncthreads();
+  red[sl][cl] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[k][cl];
+  return s;
+}
+
+// ss = scale | shift | mean | rstd (4N).  out = relu(y*scale + shift) (+ addrow).
+__global__ void __launch_bounds__(256)
+bn1d_relu_fwd_kernel(const float* __restrict__ y, int M, int N, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                     int64_t* __restrict__ nbt, float* __restrict__ ss, float* __restrict__ out, int ldo,
+                     const float* __restrict__ addrow, int ldr, int training) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, n = blockIdx.x * 32 + cl;
+  const bool ok = n < N;
+  float mean, rstd;
+  if (training) {
+    float s = 0.f;
+    if (ok)
+      for (int m = sl; m < M; m += 8) s += y[(size_t)m * N + n];
+    mean = block_colsum(s, red, sl, cl) / (float)M;
+    float q = 0.f;
+    if (ok)
+      for (int m = sl; m < M; m += 8) {
+        const float d = y[(size_t)m * N + n] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float m2 = block_colsum(q, red, sl, cl);
+    const float var = m2 / (float)M;  // biased, used to normalise
+    rstd = 1.0f / sqrtf(var + BN1_EPS);
+    if (ok && sl == 0 && rmean) {
+      const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+      rmean[n] = (1.0f - BN1_MOMENTUM) * rmean[n] + BN1_MOMENTUM * mean;
+      rvar[n] = (1.0f - BN1_MOMENTUM) * rvar[n] + BN1_MOMENTUM * unbiased;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  } else {
+    mean = ok ? rmean[n] : 0.f;
+    rstd = ok ? 1.0f / sqrtf(rvar[n] + BN1_EPS) : 0.f;
+  }
+  if (!ok) return;
+  const float sc = gamma[n] * rstd, sh = beta[n] - mean * sc;
+  if (sl == 0) { ss[n] = sc; ss[N + n] = sh; ss[2 * N + n] = mean; ss[3 * N + n] = rstd; }
+  for (int m = sl; m < M; m += 8) {
+    float a = fmaxf(fmaf(y[(size_t)m * N + n], sc, sh), 0.f);
+    if (addrow) a += addrow[(size_t)m * ldr + n];
+    out[(size_t)m * ldo + n] = a;
+  }
+}
+
+// g = (relu mask) * (ga1 + ga2);  train: gy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));
+// eval: gy = g*gamma*rstd.  dgamma = sum g*xhat, dbeta = sum g, dbias(linear) = sum gy.
+__global__ void __launch_bounds__(256)
+bn1d_relu_bwd_kernel(const float* __restrict__ ga1, int ld1, const float* __restrict__ ga2, int ld2,
+                     const float* __restrict__ y, int M, int N, const float* __restrict__ ss,
+                     const float* __restrict__ gamma, float* __restrict__ gy, float* __restrict__ dgamma,
+                     float* __restrict__ dbeta, float* __restrict__ dbias, int training) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, n = blockIdx.x * 32 + cl;
+  const bool ok = n < N;
+  float sc = 0.f, sh = 0.f, mean = 0.f, rstd = 0.f, gm = 0.f;
+  if (ok) { sc = ss[n]; sh = ss[N + n]; mean = ss[2 * N + n]; rstd = ss[3 * N + n]; gm = gamma[n]; }
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int m = sl; m < M; m += 8) {
+      const float yv = y[(size_t)m * N + n];
+      float g = ga1[(size_t)m * ld1 + n];
+      if (ga2) g += ga2[(size_t)m * ld2 + n];
+      g = fmaf(yv, sc, sh) > 0.f ? g : 0.f;
+      s1 += g;
+      s2 = fmaf(g, (yv - mean) * rstd, s2);
+    }
+  s1 = block_colsum(s1, red, sl, cl);
+  s2 = block_colsum(s2, red, sl, cl);
+  if (!ok) return;
+  if (sl == 0) {
+    dgamma[n] = s2;
+    dbeta[n] = s1;
+    dbias[n] = training ? 0.f : s1 * gm * rstd;  // train: the batch mean absorbs the bias exactly
+  }
+  const float k1 = s1 / (float)M, k2 = s2 / (float)M, gr = gm * rstd;
+  for (int m = sl; m < M; m += 8) {
+    const float yv = y[(size_t)m * N + n];
+    float g = ga1[(size_t)m * ld1 + n];
+    if (ga2) g += ga2[(size_t)m * ld2 + n];
+    g = fmaf(yv, sc, sh) > 0.f ? g : 0.f;
+    gy[(size_t)m * N + n] = training ? gr * (g - k1 - (yv - mean) * rstd * k2) : g * gr;
+  }
+}
+
+// z = mu + eps * exp(0.5 * logvar)   (vae.py:55-58)
+__global__ void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                               const float* __restrict__ eps, float* __restrict__ z, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) z[i] = mu[i] + eps[i] * expf(0.5f * logvar[i]);
+}
+
+// --------------------------------------------------------------------- network
+constexpr int LATENT = 20;
+constexpr int TDM = 256;
+
+struct LUnit { int cin, cout; };
+// enc1.0 enc1.3 enc2.0 enc2.3 enc3.0 enc3.3 bottleneck dec3.0 dec3.3 dec2.0 dec2.3 dec1.0 dec1.3
+const LUnit LU[13] = {{512, 512}, {512, 256}, {256, 256}, {256, 128}, {128, 128}, {128, 64}, {64, 64},
+                      {128, 128}, {128, 128}, {256, 256}, {256, 256}, {512, 512}, {512, 512}};
+const int TPW[3] = {64, 128, 256};  // time_proj widths
+
+inline size_t al64(size_t n) { return (n + 63) / 64 * 64; }
+
+struct LLayout {
+  size_t z, t, y, pre, emb, tp[3], x0, Y[13], ss[13], cat[3], a[13];  // a[u]: dense post-activation (where used)
+  size_t gA[13], gY, gcat[3], gx0, timescr, total;
+};
+
+LLayout latent_layout(int B) {
+  LLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += al64(n); return r; };
+  const size_t b = (size_t)B;
+  L.z = take(b * LATENT); L.t = take(2 * b); L.y = take(2 * b);
+  L.pre = take(b * TDM); L.emb = take(b * TDM);
+  for (int k = 0; k < 3; ++k) L.tp[k] = take(b * TPW[k]);
+  L.x0 = take(b * 512);
+  for (int u = 0; u < 13; ++u) {
+    L.Y[u] = take(b * LU[u].cout);
+    L.ss[u] = take(4 * (size_t)LU[u].cout);
+    L.a[u] = take(b * LU[u].cout);
+    L.gA[u] = take(b * LU[u].cout);
+  }
+  L.cat[0] = take(b * 128); L.cat[1] = take(b * 256); L.cat[2] = take(b * 512);  // dec3, dec2, dec1 inputs
+  L.gcat[0] = take(b * 128); L.gcat[1] = take(b * 256); L.gcat[2] = take(b * 512);
+  L.gY = take(b * 512);
+  L.gx0 = take(b * 512);
+  L.timescr = take(3 * b * TDM);
+  L.total = o;
+  return L;
+}
+
+// where the post-activation output of unit u is written, and where unit u reads its input
+struct Route { size_t off; int ld; };
+
+}  // namespace
+
+size_t tdx_latent_workspace_floats(int B) { return latent_layout(B).total; }
+size_t tdx_latent_infer_ss_floats(void) {
+  size_t n = 0;
+  for (int u = 0; u < 13; ++u) n += al64(2 * (size_t)LU[u].cout);
+  return n;
+}
+
+int tdx_latent_pack(const float* const* P, void* const* buffers, float* infer_ss, hipStream_t st) {
+  size_t o = 0;
+  for (int u = 0; u < 13; ++u) {
+    const int C = LU[u].cout;
+    float* ss = infer_ss + o;
+    int rc = tdx_bn_finalize(nullptr, 0, 0, 0, C, P[TDX_P_UNIT0 + 4 * u + 2], P[TDX_P_UNIT0 + 4 * u + 3],
+                             (float*)buffers[3 * u], (float*)buffers[3 * u + 1], nullptr, ss, ss + C, nullptr,
+                             nullptr, 0, reinterpret_cast<tdx_stream_t>(st));
+    if (rc) return rc;
+    o += al64(2 * (size_t)C);
+  }
+  return 0;
+}
+
+#define RC(call)            \
+  do {                      \
+    int rc__ = (call);      \
+    if (rc__) return rc__;  \
+  } while (0)
+
+namespace {
+// input of unit u and destination of its activation, as (offset, ld) into the workspace
+void routes(const LLayout& L, Route in[13], Route out[13]) {
+  // e1 -> cat1[:, 256:], e2 -> cat2[:, 128:], e3 -> cat3[:, 64:]; b+t1 -> cat3[:, :64];
+  // d3+t2 -> cat2[:, :128]; d2+t3 -> cat1[:, :256]
+  out[0] = {L.a[0], 512};          in[0] = {L.x0, 512};
+  out[1] = {L.cat[2] + 256, 512};  in[1] = out[0];
+  out[2] = {L.a[2], 256};          in[2] = out[1];
+  out[3] = {L.cat[1] + 128, 256};  in[3] = out[2];
+  out[4] = {L.a[4], 128};          in[4] = out[3];
+  out[5] = {L.cat[0] + 64, 128};   in[5] = out[4];
+  out[6] = {L.cat[0], 128};        in[6] = out[5];
+  out[7] = {L.a[7], 128};          in[7] = {L.cat[0], 128};
+  out[8] = {L.cat[1], 256};        in[8] = out[7];
+  out[9] = {L.a[9], 256};          in[9] = {L.cat[1], 256};
+  out[10] = {L.cat[2], 512};       in[10] = out[9];
+  out[11] = {L.a[11], 512};        in[11] = {L.cat[2], 512};
+  out[12] = {L.a[12], 512};        in[12] = out[11];
+}
+// time projection added to the activation of unit u (after the ReLU), or -1
+inline int addend_of(int u) { return u == 6 ? 0 : u == 8 ? 1 : u == 10 ? 2 : -1; }
+}  // namespace
+
+int tdx_latent_forward(const float* const* P, void* const* buffers, const float* z, const int64_t* t,
+                       const int64_t* y, float* out, float* ws, int B, int mode, const float* infer_ss,
+                       hipStream_t st) {
+  if (B > 4096) return TDX_E_SHAPE;
+  const LLayout L = latent_layout(B);
+  const bool infer = mode == TDX_MODE_INFER;
+  const int training = mode == TDX_MODE_TRAIN ? 1 : 0;
+  if (!infer) {
+    TDX_HIP(hipMemcpyAsync(ws + L.z, z, (size_t)B * LATENT * sizeof(float), hipMemcpyDeviceToDevice, st));
+    TDX_HIP(hipMemcpyAsync(ws + L.t, t, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    TDX_HIP(hipMemcpyAsync(ws + L.y, y, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+  }
+  RC(tdx_time_embed_only(t, y, P, ws + L.pre, ws + L.emb, B, st));
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k)
+    RC(linear_fwd(ws + L.emb, TDM, P[pw[k]], P[pw[k] + 1], ws + L.tp[k], TPW[k], B, TPW[k], TDM, 0, nullptr,
+                  nullptr, nullptr, 0, st));
+  RC(linear_fwd(z, LATENT, P[TDX_P_INIT_W], P[TDX_P_INIT_B], ws + L.x0, 512, B, 512, LATENT, 0, nullptr, nullptr,
+                nullptr, 0, st));
+  Route in[13], o[13];
+  routes(L, in, o);
+  size_t iss = 0;
+  for (int u = 0; u < 13; ++u) {
+    const int K = LU[u].cin, N = LU[u].cout, ad = addend_of(u);
+    const float* w = P[TDX_P_UNIT0 + 4 * u];
+    const float* bias = P[TDX_P_UNIT0 + 4 * u + 1];
+    const float* addrow = ad >= 0 ? ws + L.tp[ad] : nullptr;
+    const int ldr = ad >= 0 ? TPW[ad] : 0;
+    if (infer) {
+      // eval-mode BatchNorm folded into the GEMM epilogue: one launch per layer
+      const float* ss = infer_ss + iss;
+      RC(linear_fwd(ws + in[u].off, in[u].ld, w, bias, ws + o[u].off, o[u].ld, B, N, K, 1, ss, ss + N, addrow, ldr, st));
+      iss += al64(2 * (size_t)N);
+      continue;
+    }
+    RC(linear_fwd(ws + in[u].off, in[u].ld, w, bias, ws + L.Y[u], N, B, N, K, 0, nullptr, nullptr, nullptr, 0, st));
+    bn1d_relu_fwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(
+        ws + L.Y[u], B, N, P[TDX_P_UNIT0 + 4 * u + 2], P[TDX_P_UNIT0 + 4 * u + 3], (float*)buffers[3 * u],
+        (float*)buffers[3 * u + 1], (int64_t*)buffers[3 * u + 2], ws + L.ss[u], ws + o[u].off, o[u].ld, addrow,
+        ldr, training);
+    TDX_CHECK_LAUNCH();
+  }
+  return linear_fwd(ws + o[12].off, 512, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, LATENT, B, LATENT, 512, 0, nullptr,
+                    nullptr, nullptr, 0, st);
+}
+
+int tdx_latent_backward(const float* const* P, float* const* G, const float* d_out, float* ws, int B,
+                        int training, int stage_lo, int stage_hi, int ncls, hipStream_t st) {
+  const LLayout L = latent_layout(B);
+  Route in[13], o[13];
+  routes(L, in, o);
+  // gradient w.r.t. the activation of unit u: (pointer, ld), plus an optional second addend (skip path)
+  struct GSrc { size_t off; int ld; long off2; int ld2; };
+  GSrc gs[13];
+  for (int u = 0; u < 13; ++u) gs[u] = {L.gA[u], LU[u].cout, -1, 0};
+  gs[10] = {L.gcat[2], 512, -1, 0};                    // d(d2 + t3) = gcat1[:, :256]
+  gs[8] = {L.gcat[1], 256, -1, 0};                     // d(d3 + t2) = gcat2[:, :128]
+  gs[6] = {L.gcat[0], 128, -1, 0};                     // d(b + t1)  = gcat3[:, :64]
+  gs[5].off2 = (long)(L.gcat[0] + 64); gs[5].ld2 = 128;   // e3: from the bottleneck + the skip into dec3
+  gs[3].off2 = (long)(L.gcat[1] + 128); gs[3].ld2 = 256;  // e2
+  gs[1].off2 = (long)(L.gcat[2] + 256); gs[1].ld2 = 512;  // e1
+  // where the input gradient of unit u goes
+  auto gin = [&](int u) -> Route {
+    switch (u) {
+      case 11: return {L.gcat[2], 512};
+      case 9: return {L.gcat[1], 256};
+      case 7: return {L.gcat[0], 128};
+      case 0: return {L.gx0, 512};
+      default: return {L.gA[u - 1], LU[u - 1].cout};
+    }
+  };
+  float* gY = ws + L.gY;
+  for (int s = stage_lo; s < stage_hi; ++s) {
+    if (s == 0) {  // final_fc
+      RC(linear_wgrad(d_out, LATENT, ws + o[12].off, 512, G[TDX_P_FINAL_W], B, LATENT, 512, st));
+      RC(colsum(d_out, LATENT, B, LATENT, G[TDX_P_FINAL_B], st));
+      RC(linear_dgrad(d_out, LATENT, P[TDX_P_FINAL_W], ws + L.gA[12], 512, B, LATENT, 512, 0, st));
+    } else if (s <= 13) {
+      const int u = 13 - s, K = LU[u].cin, N = LU[u].cout;
+      const int pi = TDX_P_UNIT0 + 4 * u;
+      bn1d_relu_bwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(
+          ws + gs[u].off, gs[u].ld, gs[u].off2 >= 0 ? ws + gs[u].off2 : nullptr, gs[u].ld2, ws + L.Y[u], B, N,
+          ws + L.ss[u], P[pi + 2], gY, G[pi + 2], G[pi + 3], G[pi + 1], training);
+      TDX_CHECK_LAUNCH();
+      RC(linear_wgrad(gY, N, ws + in[u].off, in[u].ld, G[pi], B, N, K, st));
+      const Route gi = gin(u);
+      RC(linear_dgrad(gY, N, P[pi], ws + gi.off, gi.ld, B, N, K, 0, st));
+    } else {  // initial_fc and the time / class path
+      RC(linear_wgrad(ws + L.gx0, 512, ws + L.z, LATENT, G[TDX_P_INIT_W], B, 512, LATENT, st));
+      RC(colsum(ws + L.gx0, 512, B, 512, G[TDX_P_INIT_B], st));
+      const float* gt[3] = {ws + L.gcat[0], ws + L.gcat[1], ws + L.gcat[2]};
+      const int ldg[3] = {128, 256, 512};
+      RC(tdx_time_embed_bwd_ex(reinterpret_cast<const int64_t*>(ws + L.t), reinterpret_cast<const int64_t*>(ws + L.y),
+                               P, G, ws + L.pre, ws + L.emb, gt, ldg, TPW, ws + L.timescr, B, ncls, st));
+    }
+  }
+  return 0;
+}
+
+int tdx_latent_tensor(int B, const char* name, size_t* off, size_t* numel) {
+  const LLayout L = latent_layout(B);
+  const size_t b = (size_t)B;
+  std::string n(name);
+  struct { const char* nm; size_t off, cnt; } fixed[] = {
+      {"x0", L.x0, b * 512}, {"emb", L.emb, b * TDM}, {"t1", L.tp[0], b * 64}, {"t2", L.tp[1], b * 128},
+      {"t3", L.tp[2], b * 256}, {"cat3", L.cat[0], b * 128}, {"cat2", L.cat[1], b * 256}, {"cat1", L.cat[2], b * 512}};
+  for (auto& f : fixed)
+    if (n == f.nm) { *off = f.off; *numel = f.cnt; return 0; }
+  if (n.size() >= 2 && n[0] == 'Y') {
+    const int i = atoi(n.c_str() + 1);
+    if (i < 0 || i > 12) return TDX_E_BADARG;
+    *off = L.Y[i]; *numel = b * LU[i].cout; return 0;
+  }
+  return TDX_E_BADARG;
+}
+
+// ------------------------------------------------------------------- C ABI pieces
+extern "C" int tdx_linear_fwd(const float* x, int ldx, const float* w, const float* bias, float* out, int ldo,
+                              int M, int N, int K, int act, tdx_stream_t stream) {
+  if (!x || !w || !out || ldx < K || ldo < N || act < 0 || act > 2) return TDX_E_BADARG;
+  return linear_fwd(x, ldx, w, bias, out, ldo, M, N, K, act, nullptr, nullptr, nullptr, 0, to_stream(stream));
+}
+
+extern "C" int tdx_linear_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* w, float* gx,
+                              int ldgx, float* dw, float* db, int M, int N, int K, tdx_stream_t stream) {
+  if (!gy || M <= 0 || N <= 0 || K <= 0 || ldgy < N) return TDX_E_BADARG;
+  hipStream_t st = to_stream(stream);
+  if (dw) {
+    if (!x || ldx < K) return TDX_E_BADARG;
+    RC(linear_wgrad(gy, ldgy, x, ldx, dw, M, N, K, st));
+  }
+  if (db) RC(colsum(gy, ldgy, M, N, db, st));
+  if (gx) {
+    if (!w || ldgx < K) return TDX_E_BADARG;
+    RC(linear_dgrad(gy, ldgy, w, gx, ldgx, M, N, K, 0, st));
+  }
+  return 0;
+}
+
+extern "C" size_t tdx_vae_workspace_floats(int batch, int hidden_dim) {
+  return batch > 0 && hidden_dim > 0 ? al64((size_t)batch * hidden_dim) : 0;
+}
+
+// vae.py:51-53.  params: fc1.w fc1.b fc21.w fc21.b fc22.w fc22.b
+extern "C" int tdx_vae_encode(const float* x, const void* const* params, float* mu, float* logvar,
+                              float* workspace, int batch, int input_dim, int hidden_dim, int latent_dim,
+                              tdx_stream_t stream) {
+  if (!x || !params || !mu || !logvar || !workspace || batch <= 0) return TDX_E_BADARG;
+  const float* const* P = reinterpret_cast<const float* const*>(params);
+  hipStream_t st = to_stream(stream);
+  RC(linear_fwd(x, input_dim, P[0], P[1], workspace, hidden_dim, batch, hidden_dim, input_dim, 1, nullptr, nullptr,
+                nullptr, 0, st));
+  RC(linear_fwd(workspace, hidden_dim, P[2], P[3], mu, latent_dim, batch, latent_dim, hidden_dim, 0, nullptr,
+                nullptr, nullptr, 0, st));
+  return linear_fwd(workspace, hidden_dim, P[4], P[5], logvar, latent_dim, batch, latent_dim, hidden_dim, 0, nullptr,
+                    nullptr, nullptr, 0, st);
+}
+
+// vae.py:55-58 with the noise supplied by the caller
+extern "C" int tdx_vae_reparameterize(const float* mu, const float* logvar, const float* eps, float* z,
+                                      int64_t n, tdx_stream_t stream) {
+  if (!mu || !logvar || !eps || !z || n <= 0) return TDX_E_BADARG;
+  reparam_kernel<<<cdiv(n, 256), 256, 0, to_stream(stream)>>>(mu, logvar, eps, z, n);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// vae.py:60-62.  params: fc3.w fc3.b fc4.w fc4.b
+extern "C" int tdx_vae_decode(const float* z, const void* const* params, float* out, float* workspace,
+                              int batch, int input_dim, int hidden_dim, int latent_dim, tdx_stream_t stream) {
+  if (!z || !params || !out || !workspace || batch <= 0) return TDX_E_BADARG;
+  const float* const* P = reinterpret_cast<const float* const*>(params);
+  hipStream_t st = to_stream(stream);
+  RC(linear_fwd(z, latent_dim, P[0], P[1], workspace, hidden_dim, batch, hidden_dim, latent_dim, 1, nullptr, nullptr,
+                nullptr, 0, st));
+  return linear_fwd(workspace, hidden_dim, P[2], P[3], out, input_dim, batch, input_dim, hidden_dim, 2, nullptr,
+                    nullptr, nullptr, 0, st);
+}

@@ -192,14 +192,15 @@ int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float
 // ------------------------------------------------------------------ backward
 // dW[o][j] = sum_n g[n][o] * x[n][j];  db[o] = sum_n g[n][o]     (thread per (o, j))
 __global__ void lin_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                 float* __restrict__ dw, float* __restrict__ db, int B, int O, int J) {
+                                 float* __restrict__ dw, float* __restrict__ db, int B, int O, int J,
+                                 int ldg) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= O * J) return;
   const int o = idx / J, j = idx - o * J;
   float s = 0.f, sb = 0.f;
 #pragma unroll 8
   for (int n = 0; n < B; ++n) {
-    const float gv = g[(size_t)n * O + o];
+    const float gv = g[(size_t)n * ldg + o];
     s = fmaf(gv, x[(size_t)n * J + j], s);
     sb += gv;
   }
@@ -209,13 +210,13 @@ __global__ void lin_wgrad_kernel(const float* __restrict__ g, const float* __res
 
 // gx[n][j] (+)= sum_o g[n][o] * W[o][j]     (thread per (n, j))
 __global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w,
-                                 float* __restrict__ gx, int B, int O, int J, int accumulate) {
+                                 float* __restrict__ gx, int B, int O, int J, int accumulate, int ldg) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * J) return;
   const int n = idx / J, j = idx - n * J;
   float s = accumulate ? gx[idx] : 0.f;
 #pragma unroll 8
-  for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * O + o], w[(size_t)o * J + j], s);
+  for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * ldg + o], w[(size_t)o * J + j], s);
   gx[idx] = s;
 }
 
@@ -283,41 +284,39 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
   const int ok[3] = {64, 128, 256};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k) {
-    lin_wgrad_kernel<<<cdiv(ok[k] * TDL, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], TDL);
+    lin_wgrad_kernel<<<cdiv(ok[k] * TDL, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], TDL, ok[k]);
     TDX_CHECK_LAUNCH();
-    lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TDL, k > 0);
+    lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TDL, k > 0, ok[k]);
     TDX_CHECK_LAUNCH();
   }
   silu_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(pre, h, B * TDL);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TDL, TDL);
+  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TDL, TDL, TDL);
   TDX_CHECK_LAUNCH();
-  lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TDL, TDL, 0);
+  lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TDL, TDL, 0, TDL);
   TDX_CHECK_LAUNCH();
   silu_bwd_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_h, pre, B * TDL);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_h, sin, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, TDL, TDL);
+  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_h, sin, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, TDL, TDL, TDL);
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-// scratch: g_emb (B*time_dim) | h (B*time_dim) | g_h (B*time_dim)
-int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
-                       const float* sin, const float* pre, const float* emb, const float* g_t1,
-                       const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st) {
-  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
+// kind-0 time path backward with the three projection gradients given as strided views
+// (g_tk[n*ldg[k] + o], o < widths[k]).  scratch: g_emb (B*256) | h (B*256) | g_h (B*256)
+int tdx_time_embed_bwd_ex(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+                          const float* pre, const float* emb, const float* const* gk, const int* ldg,
+                          const int* widths, float* scratch, int B, int ncls, hipStream_t st) {
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * TD;
   float* g_h = scratch + (size_t)2 * B * TD;
-  const float* gk[3] = {g_t1, g_t2, g_t3};
-  const int ok[3] = {128, 256, 512};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k) {
-    lin_wgrad_kernel<<<cdiv(ok[k] * TD, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
-                                                            ok[k], TD);
+    lin_wgrad_kernel<<<cdiv(widths[k] * TD, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
+                                                                widths[k], TD, ldg[k]);
     TDX_CHECK_LAUNCH();
-    lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TD, k > 0);
+    lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, widths[k], TD, k > 0,
+                                                        ldg[k]);
     TDX_CHECK_LAUNCH();
   }
   if (ncls > 0 && y) {
@@ -326,12 +325,30 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
   }
   silu_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(pre, h, B * TD);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TD * TD, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B,
-                                                       TD, TD);
+  lin_wgrad_kernel<<<cdiv(TD * TD, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TD, TD, TD);
   TDX_CHECK_LAUNCH();
-  lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0);
+  lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0, TD);
   TDX_CHECK_LAUNCH();
   time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+                       const float* sin, const float* pre, const float* emb, const float* g_t1,
+                       const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
+                       hipStream_t st) {
+  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
+  const float* gk[3] = {g_t1, g_t2, g_t3};
+  const int widths[3] = {128, 256, 512};
+  return tdx_time_embed_bwd_ex(t, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st);
+}
+
+// emb only (kind-0 formula): the latent model applies its own projection widths
+int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
+                        int B, hipStream_t st) {
+  time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
+                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb);
   TDX_CHECK_LAUNCH();
   return 0;
 }

@@ -137,21 +137,26 @@ struct tdx_unet {
 };
 
 extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes) {
-  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 1) return TDX_E_BADARG;
-  if (kind == 1 && num_classes != 0) return TDX_E_BADARG;
+  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2) return TDX_E_BADARG;
+  if (kind == TDX_UNET_LAION && num_classes != 0) return TDX_E_BADARG;
+  if (kind == TDX_UNET_LATENT_MLP && num_classes <= 0) return TDX_E_BADARG;
   tdx_unet* u = new (std::nothrow) tdx_unet();
   if (!u) return TDX_E_BADARG;
   u->max_batch = max_batch;
   u->num_classes = num_classes;
   u->kind = kind;
-  u->spec = &SPECS[kind];
-  size_t o = 0, so = 0;
-  for (int i = 0; i < 13; ++i) {
-    const UnitDef& d = u->spec->units[i];
-    const size_t n = (size_t)d.cin * d.cout * 9;
-    u->wf_off[i] = o; o += align64(n);
-    u->wd_off[i] = o; o += align64(n);
-    u->iss_off[i] = so; so += align64(2 * (size_t)d.cout);
+  u->spec = kind == TDX_UNET_LATENT_MLP ? nullptr : &SPECS[kind];
+  size_t o = 64, so = 0;
+  if (u->spec) {
+    for (int i = 0; i < 13; ++i) {
+      const UnitDef& d = u->spec->units[i];
+      const size_t n = (size_t)d.cin * d.cout * 9;
+      u->wf_off[i] = o; o += align64(n);
+      u->wd_off[i] = o; o += align64(n);
+      u->iss_off[i] = so; so += align64(2 * (size_t)d.cout);
+    }
+  } else {
+    so = tdx_latent_infer_ss_floats();  // the MLP needs no weight packs
   }
   hipError_t e = hipMalloc(&u->wpack, o * sizeof(float));
   if (e != hipSuccess) { delete u; return (int)e; }
@@ -195,6 +200,7 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
 extern "C" size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode) {
   (void)mode;
   if (!u || batch <= 0 || batch > u->max_batch) return 0;
+  if (!u->spec) return tdx_latent_workspace_floats(batch) * sizeof(float);
   return make_layout(*u->spec, batch).total * sizeof(float);
 }
 
@@ -207,6 +213,7 @@ extern "C" int tdx_unet_backward_stages(void) { return N_STAGES; }
 extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, size_t* offset_floats,
                                size_t* numel) {
   if (!u || !name || !offset_floats || !numel || batch <= 0 || batch > u->max_batch) return TDX_E_BADARG;
+  if (!u->spec) return tdx_latent_tensor(batch, name, offset_floats, numel);
   const NetSpec& S = *u->spec;
   const Layout L = make_layout(S, batch);
   const size_t b = (size_t)batch;
@@ -251,6 +258,14 @@ extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, s
 static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffers,
                      tdx_stream_t stream) {
   const float* const* P = reinterpret_cast<const float* const*>(params);
+  if (!u->spec) {
+    if (buffers) {
+      int rc = tdx_latent_pack(P, buffers, u->infer_ss, to_stream(stream));
+      if (rc) return rc;
+    }
+    u->packed = buffers != nullptr;
+    return 0;
+  }
   for (int i = 0; i < 13; ++i) {
     const UnitDef& d = u->spec->units[i];
     int rc = tdx_pack_conv3x3_pad(P[TDX_P_UNIT0 + 4 * i], u->wpack + u->wf_off[i],
@@ -290,6 +305,20 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   if (mode < TDX_MODE_TRAIN || mode > TDX_MODE_INFER) return TDX_E_BADARG;
   const bool needs_cond = u->kind == 1 || u->num_classes > 0;
   if (needs_cond != (cond != nullptr)) return TDX_E_BADARG;
+  if (!u->spec) {  // latent MLP
+    if (workspace_bytes < tdx_latent_workspace_floats(batch) * sizeof(float)) return TDX_E_WORKSPACE;
+    if (mode == TDX_MODE_INFER && !u->packed) {
+      int rc = pack_impl(u, params, buffers, stream);
+      if (rc) return rc;
+    }
+    int rc = tdx_latent_forward(reinterpret_cast<const float* const*>(params), buffers, x, t,
+                                static_cast<const int64_t*>(cond), out, reinterpret_cast<float*>(workspace), batch,
+                                mode, u->infer_ss, to_stream(stream));
+    if (rc) return rc;
+    u->saved_batch = mode == TDX_MODE_INFER ? 0 : batch;
+    u->saved_mode = mode;
+    return 0;
+  }
   const NetSpec& S = *u->spec;
   const Layout L = make_layout(S, batch);
   if (workspace_bytes < L.total * sizeof(float)) return TDX_E_WORKSPACE;
@@ -389,6 +418,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   if (!u || !params || !grads || !d_out || !workspace) return TDX_E_BADARG;
   if (batch != u->saved_batch || u->saved_mode == TDX_MODE_INFER || u->saved_mode < 0) return TDX_E_STATE;
   if (stage_lo < 0 || stage_hi > N_STAGES || stage_lo >= stage_hi) return TDX_E_BADARG;
+  if (!u->spec) {
+    if (workspace_bytes < tdx_latent_workspace_floats(batch) * sizeof(float)) return TDX_E_WORKSPACE;
+    return tdx_latent_backward(reinterpret_cast<const float* const*>(params), reinterpret_cast<float* const*>(grads),
+                               d_out, reinterpret_cast<float*>(workspace), batch,
+                               u->saved_mode == TDX_MODE_TRAIN ? 1 : 0, stage_lo, stage_hi, u->num_classes,
+                               to_stream(stream));
+  }
   const NetSpec& S = *u->spec;
   const Layout L = make_layout(S, batch);
   if (workspace_bytes < L.total * sizeof(float)) return TDX_E_WORKSPACE;

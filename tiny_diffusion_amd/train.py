@@ -40,11 +40,12 @@ def merge_ranges(ranges):
     return out
 
 
-def plan_buckets(offsets, cond: bool, bucket_floats: int, time_name: str = "time_embedding"):
+def plan_buckets(offsets, cond: bool, bucket_floats: int, time_name: str = "time_embedding",
+                 init_name: str = "initial_conv", final_name: str = "final_conv"):
     """Group consecutive backward stages (unet.backward_stage_params) into buckets of at
     least ``bucket_floats`` gradient elements.  Returns [(last_stage, [(lo, hi), ...])]:
     after ``last_stage`` has run, those slices of the flat gradient are final."""
-    stages = backward_stage_params(cond, time_name)
+    stages = backward_stage_params(cond, time_name, init_name, final_name)
     buckets: List[Tuple[int, List[Tuple[int, int]]]] = []
     cur: List[Tuple[int, int]] = []
     size = 0
@@ -117,7 +118,9 @@ class TrainStep:
         self.pg = process_group
         self.philox_seed = philox_seed
         self._flatten()
-        self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats, model._arch.time_name)
+        a = model._arch
+        self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats, a.time_name, a.init_name,
+                                    a.final_name)
         assert self.buckets[-1][0] == self.n_stages - 1
         self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
         self.world = self.reducer.world

@@ -22,14 +22,16 @@ from ._lib import lib, check
 
 TIME_DIM = 256
 MODE_TRAIN, MODE_EVAL_GRAD, MODE_INFER = 0, 1, 2
-KIND_MNIST, KIND_LAION = 0, 1
+KIND_MNIST, KIND_LAION, KIND_LATENT = 0, 1, 2
 
 
 class _Arch:
     """Shape of one reference NoiseModel (mirrors SPECS[] in csrc/unet.hip)."""
 
-    def __init__(self, kind, in_shape, time_dim, time_name, x0, enc, bottleneck, dec, ceil_pool):
+    def __init__(self, kind, in_shape, time_dim, time_name, x0, enc, bottleneck, dec, ceil_pool,
+                 init_name="initial_conv", final_name="final_conv"):
         self.kind = kind
+        self.init_name, self.final_name = init_name, final_name
         self.in_shape = in_shape          # (C, H, W) of x and of the prediction
         self.time_dim = time_dim
         self.time_name = time_name        # module name of the time MLP
@@ -53,22 +55,34 @@ _UNIT_PREFIX = (
 )
 
 
+# latent_diffusion.py:16-105: stages are (name, in, mid, out) of two Linear+BatchNorm1d+ReLU units
+ARCH_LATENT = _Arch(KIND_LATENT, (20,), 256, "time_embedding", 512,
+                    (("enc1", 512, 512, 256), ("enc2", 256, 256, 128), ("enc3", 128, 128, 64)), 64,
+                    (("dec3", 128, 128, 128), ("dec2", 256, 256, 256), ("dec1", 512, 512, 512)), False,
+                    init_name="initial_fc", final_name="final_fc")
+
+
+def _lin_bn_relu(cin, cout):
+    return [nn.Linear(cin, cout), nn.BatchNorm1d(cout), nn.ReLU()]
+
+
 def _conv_bn_relu(cin, cout):
     return [nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.ReLU()]
 
 
-def param_slot_names(cond: bool, time_name: str = "time_embedding") -> List[Optional[str]]:
+def param_slot_names(cond: bool, time_name: str = "time_embedding", init_name: str = "initial_conv",
+                     final_name: str = "final_conv") -> List[Optional[str]]:
     """state_dict key of every TDX_P_* slot (None where the slot is unused)."""
     names: List[Optional[str]] = [
         f"{time_name}.0.weight", f"{time_name}.0.bias",
         f"{time_name}.2.weight", f"{time_name}.2.bias",
         "class_embedding.weight" if cond else None,
-        "initial_conv.weight", "initial_conv.bias",
+        f"{init_name}.weight", f"{init_name}.bias",
     ]
     for stage, idx in _UNIT_PREFIX:
         names += [f"{stage}.{idx}.weight", f"{stage}.{idx}.bias",
                   f"{stage}.{idx + 1}.weight", f"{stage}.{idx + 1}.bias"]
-    names += ["final_conv.weight", "final_conv.bias"]
+    names += [f"{final_name}.weight", f"{final_name}.bias"]
     for k in (1, 2, 3):
         names += [f"time_proj{k}.weight", f"time_proj{k}.bias"]
     return names
@@ -82,14 +96,15 @@ def buffer_slot_names() -> List[str]:
     return out
 
 
-def backward_stage_params(cond: bool, time_name: str = "time_embedding") -> List[List[str]]:
+def backward_stage_params(cond: bool, time_name: str = "time_embedding", init_name: str = "initial_conv",
+                          final_name: str = "final_conv") -> List[List[str]]:
     """Parameters whose gradient is final after each backward stage
     (tdx_unet_backward stage order): used to bucket the gradient all-reduce."""
-    stages = [["final_conv.weight", "final_conv.bias"]]
+    stages = [[f"{final_name}.weight", f"{final_name}.bias"]]
     for stage, idx in reversed(_UNIT_PREFIX):
         stages.append([f"{stage}.{idx}.weight", f"{stage}.{idx}.bias",
                        f"{stage}.{idx + 1}.weight", f"{stage}.{idx + 1}.bias"])
-    last = ["initial_conv.weight", "initial_conv.bias",
+    last = [f"{init_name}.weight", f"{init_name}.bias",
             f"{time_name}.0.weight", f"{time_name}.0.bias",
             f"{time_name}.2.weight", f"{time_name}.2.bias"]
     if cond:
@@ -188,6 +203,37 @@ class NoiseModelBase(nn.Module):
         self.time_dim = time_dim
         self.num_classes = int(num_classes)
         self._arch = arch
+        if arch.kind == KIND_LATENT:
+            self._init_latent(arch, time_dim)
+        else:
+            self._init_unet(arch, time_dim)
+        cond = self.num_classes > 0
+        self._slot_names = param_slot_names(cond, arch.time_name, arch.init_name, arch.final_name)
+        self._buf_names = buffer_slot_names()
+        self._param_order = [n for n in self._slot_names if n is not None]
+        self._plans = {}
+        self._ptab_p, self._ptab_b, self._ptab_g = _PtrTable(), _PtrTable(), _PtrTable()
+        self._grad_flat = None
+        self._grad_views = None
+        self._buf_epoch = 0
+
+    def _init_latent(self, arch, time_dim):
+        # registration order == latent_diffusion.py:23-105
+        if self.num_classes <= 0:
+            raise ValueError("the latent noise model is class-conditional (num_classes > 0)")
+        self.time_embedding = nn.Sequential(nn.Linear(1, time_dim), nn.SiLU(), nn.Linear(time_dim, time_dim))
+        self.class_embedding = nn.Embedding(self.num_classes, time_dim)
+        self.initial_fc = nn.Linear(arch.in_shape[0], arch.x0)
+        for name, cin, mid, cout in arch.enc:
+            setattr(self, name, nn.Sequential(*_lin_bn_relu(cin, mid), *_lin_bn_relu(mid, cout)))
+        self.bottleneck = nn.Sequential(*_lin_bn_relu(arch.bottleneck, arch.bottleneck))
+        for name, cin, mid, cout in arch.dec:
+            setattr(self, name, nn.Sequential(*_lin_bn_relu(cin, mid), *_lin_bn_relu(mid, cout)))
+        self.final_fc = nn.Linear(512, arch.in_shape[0])
+        for k, c in ((1, 64), (2, 128), (3, 256)):
+            setattr(self, f"time_proj{k}", nn.Linear(time_dim, c))
+
+    def _init_unet(self, arch, time_dim):
         # registration order == reference (diffusion.py:19-107,
         # conditional_diffusion_laion.py:239-301): identical state_dict order and identical
         # default init under the same seed
@@ -211,16 +257,6 @@ class NoiseModelBase(nn.Module):
         if arch.kind == KIND_LAION:  # registered after the projections in the reference
             self.pool = nn.MaxPool2d(2)
             self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-
-        cond = self.num_classes > 0
-        self._slot_names = param_slot_names(cond, arch.time_name)
-        self._buf_names = buffer_slot_names()
-        self._param_order = [n for n in self._slot_names if n is not None]
-        self._plans = {}
-        self._ptab_p, self._ptab_b, self._ptab_g = _PtrTable(), _PtrTable(), _PtrTable()
-        self._grad_flat = None
-        self._grad_views = None
-        self._buf_epoch = 0
 
     # ---------------------------------------------------------------- plumbing
     def _named(self):
@@ -273,9 +309,9 @@ class NoiseModelBase(nn.Module):
             raise _lib.TdxError(
                 "tiny_diffusion_amd runs on MI355X only: got a CPU tensor and there is no "
                 "CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
-        shp = self._arch.in_shape
-        if x.dim() != 4 or tuple(x.shape[1:]) != shp:
-            raise ValueError(f"x must be (B,{shp[0]},{shp[1]},{shp[2]}), got {tuple(x.shape)}")
+        shp = tuple(self._arch.in_shape)
+        if x.dim() != 1 + len(shp) or tuple(x.shape[1:]) != shp:
+            raise ValueError(f"x must be (B,{','.join(map(str, shp))}), got {tuple(x.shape)}")
         if t.shape != (x.shape[0],):
             raise ValueError("t must have shape (B,)")
         if self._arch.kind == KIND_LAION:
