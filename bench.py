@@ -196,6 +196,51 @@ def laion_extras(steps: int = 20, warmup: int = 5):
     return out
 
 
+def latent_extras(steps: int = 200, warmup: int = 20):
+    """SURVEY.md 8(f) f4 (the model BASELINE.json configs[3] actually refers to): training
+    step of the latent MLP noise model at the reference's batch 128 (vae.encode + reparameterize +
+    q_sample + fwd + MSE + bwd + Adam, latent_diffusion.py:199-222) and the 1000-step reverse
+    chain + vae.decode for n=16 (latent_diffusion.py:308-347).  Launch-latency bound by nature."""
+    from tiny_diffusion_amd.latent_diffusion import VAE, ForwardProcess, NoiseModel, VAEConfig, sample
+    from tiny_diffusion_amd.train import TrainStep
+
+    torch.manual_seed(0)
+    fp = ForwardProcess()
+    vae = VAE(VAEConfig()).cuda().eval()
+    model = NoiseModel().cuda().train()
+    ts = TrainStep(model, fp, lr=1e-3)
+    out = {}
+    for B in (128, 1024):
+        x = torch.rand(B, 784, device="cuda") * 2 - 1
+        y = torch.randint(0, 10, (B,), device="cuda")
+
+        def one():
+            mu, logvar = vae.encode(x)
+            return ts.step(vae.reparameterize(mu, logvar), y)
+
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lv = loss.item()
+        if not (lv == lv) or lv > 1e3:
+            raise SystemExit(f"latent training diverged in the benchmark: loss {lv}")
+        out[f"train_B{B}"] = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+    model.eval()
+    y16 = torch.randint(0, 10, (16,), device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img = sample(vae, model, fp, "cuda", n_samples=16, y=y16, use_graph=True, philox_seed=3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(img).all()
+    out["sample_n16_s_per_1000_steps"] = round(time.perf_counter() - t0, 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +341,7 @@ def main():
                              "n16": round(sample_latency(model, fp, 16), 3),
                              "n64": round(sample_latency(model, fp, 64), 3)}
             res["laion_unet"] = laion_extras()
+            res["latent_mlp"] = latent_extras()
         print(json.dumps(res))
     if use_dist:
         torch.distributed.destroy_process_group()

@@ -3,8 +3,8 @@
 //
 // 2.8 MFLOP per sample forward: nothing here is throughput-bound, the cost is the length of the
 // dependent launch chain.  So the building blocks are few and generic:
-//   * one fp32 register-tiled GEMM (64x64x16, 4x4 per thread) with operand-layout template
-//     flags, serving Linear forward (X W^T), input gradient (gY W) and weight gradient (gY^T X),
+//   * one fp32 GEMM shaped for latency (32x32 tiles, split-K over the waves of a workgroup,
+//     register prefetch; see gemm_kernel) with operand-layout template flags, serving Linear forward (X W^T), input gradient (gY W) and weight gradient (gY^T X),
 //     with a fused epilogue: + bias, eval-mode BatchNorm folded to scale/shift, ReLU / sigmoid,
 //     + per-row addend (the time signal), strided output (writes straight into the concat
 //     buffers, latent_diffusion.py:124-126);
@@ -17,8 +17,9 @@
 
 namespace {
 
-constexpr int GT = 64;   // tile edge
-constexpr int GK = 16;   // k-tile
+constexpr int GT = 32;    // output tile edge (one workgroup)
+constexpr int GKC = 128;  // k-chunk staged per iteration; each of the 4 waves reduces a quarter of it
+constexpr int GLD = GT + 4;
 constexpr float BN1_EPS = 1e-5f;
 constexpr float BN1_MOMENTUM = 0.1f;
 
@@ -34,80 +35,117 @@ struct GemmArgs {
   int accumulate;        // C += result
 };
 
+// These GEMMs are tiny (<= 128 x 512 x 512) and sit on a dependent chain, so the kernel is
+// shaped for latency, not throughput: a 32x32 output tile per workgroup (many workgroups even
+// for a 128-row batch), the reduction dimension split over the four waves (each thread keeps a
+// 4x4 partial tile for its wave's quarter of every 128-deep chunk), the next chunk's global
+// loads in flight in registers while the current one is reduced, and one LDS reduction of the
+// four partial tiles at the end.  K = 512 is four dependent load round trips instead of 32.
 // A_KC: A(m,k) = A[m*lda + k] else A[k*lda + m];  B_KC: B(k,n) = B[n*ldb + k] else B[k*ldb + n]
+__device__ inline void load4(const float* __restrict__ src, bool vec, bool row_ok, int c, int C, float* v) {
+  if (vec && row_ok && c + 3 < C) {  // one 16-byte load
+    const float4 q = *reinterpret_cast<const float4*>(src);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (row_ok && c + i < C) ? src[i] : 0.f;
+  }
+}
+
+template <bool KC>
+__device__ inline void stage_load(const float* __restrict__ P, int ld, int r0, int R, int k0, int K, int t,
+                                  float (&v)[16]) {
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+  if (KC) {  // element (r, k) at P[r*ld + k]: consecutive lanes take consecutive ROWS (16 B each), so the
+             // transposing LDS store below is conflict-free; the data is L2-resident and tiny, the
+             // partially used cache lines cost less than 32-way bank conflicts did
+    const int r = r0 + (t & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + ((t >> 5) + 8 * j) * 4;
+      load4(P + (size_t)r * ld + k, vec, r < R, k, K, &v[j * 4]);
+    }
+  } else {   // element (r, k) at P[k*ld + r]: 8 threads x float4 along r, 32 k per pass
+    const int r = r0 + (t & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + (t >> 3) + 32 * j;
+      load4(P + (size_t)k * ld + r, vec, k < K, r, R, &v[j * 4]);
+    }
+  }
+}
+
+template <bool KC>
+__device__ inline void stage_store(float (*S)[GLD], int t, const float (&v)[16]) {
+  if (KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) S[((t >> 5) + 8 * j) * 4 + i][t & 31] = v[j * 4 + i];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(&S[(t >> 3) + 32 * j][(t & 7) * 4]) =
+          make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
+  }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[GK][GT + 4];
-  __shared__ __attribute__((aligned(16))) float Bs[GK][GT + 4];
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  __shared__ __attribute__((aligned(16))) float As[GKC][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[GKC][GLD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, tx = lane & 7, ty = lane >> 3;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-
-  for (int k0 = 0; k0 < g.K; k0 += GK) {
-    if (A_KC) {
-      const int r = t >> 2, c4 = (t & 3) * 4, m = m0 + r;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + c4 + i;
-        As[c4 + i][r] = (m < g.M && k < g.K) ? g.A[(size_t)m * g.lda + k] : 0.f;
-      }
-    } else {
-      const int kk = t >> 4, c4 = (t & 15) * 4, k = k0 + kk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + c4 + i;
-        As[kk][c4 + i] = (m < g.M && k < g.K) ? g.A[(size_t)k * g.lda + m] : 0.f;
-      }
-    }
-    if (B_KC) {
-      const int r = t >> 2, c4 = (t & 3) * 4, n = n0 + r;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + c4 + i;
-        Bs[c4 + i][r] = (n < g.N && k < g.K) ? g.B[(size_t)n * g.ldb + k] : 0.f;
-      }
-    } else {
-      const int kk = t >> 4, c4 = (t & 15) * 4, k = k0 + kk;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = n0 + c4 + i;
-        Bs[kk][c4 + i] = (n < g.N && k < g.K) ? g.B[(size_t)k * g.ldb + n] : 0.f;
-      }
-    }
+  float pa[16], pb[16];
+  stage_load<A_KC>(g.A, g.lda, m0, g.M, 0, g.K, t, pa);
+  stage_load<B_KC>(g.B, g.ldb, n0, g.N, 0, g.K, t, pb);
+  for (int k0 = 0; k0 < g.K; k0 += GKC) {
+    __syncthreads();  // the previous chunk has been consumed
+    stage_store<A_KC>(As, t, pa);
+    stage_store<B_KC>(Bs, t, pb);
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < GK; ++kk) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+    if (k0 + GKC < g.K) {  // next chunk's loads fly while this one is reduced
+      stage_load<A_KC>(g.A, g.lda, m0, g.M, k0 + GKC, g.K, t, pa);
+      stage_load<B_KC>(g.B, g.ldb, n0, g.N, k0 + GKC, g.K, t, pb);
+    }
+    const int kb = wave * (GKC / 4);
+#pragma unroll 8
+    for (int kk = 0; kk < GKC / 4; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[kb + kk][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[kb + kk][tx * 4]);
       const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
     }
-    __syncthreads();
   }
+  // reduce the four waves' partial tiles (fixed order: deterministic), then the epilogue
+  __syncthreads();
+  float(*Red)[GT * GT] = reinterpret_cast<float(*)[GT * GT]>(&As[0][0]);  // 4 x 1024 floats <= sizeof(As)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= g.M) continue;
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4*>(&Red[wave][(ty * 4 + i) * GT + tx * 4]) =
+        make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= g.N) continue;
-      float v = acc[i][j];
-      if (g.bias) v += g.bias[n];
-      if (g.scale) v = fmaf(v, g.scale[n], g.shift[n]);
-      if (g.act == 1) v = fmaxf(v, 0.f);
-      else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-      if (g.addrow) v += g.addrow[(size_t)m * g.ldr + n];
-      float* dst = g.C + (size_t)m * g.ldc + n;
-      *dst = g.accumulate ? *dst + v : v;
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int e = q * 256 + t, mi = e >> 5, ni = e & 31;  // consecutive threads -> consecutive columns
+    const int m = m0 + mi, n = n0 + ni;
+    if (m >= g.M || n >= g.N) continue;
+    float v = ((Red[0][e] + Red[1][e]) + Red[2][e]) + Red[3][e];
+    if (g.bias) v += g.bias[n];
+    if (g.scale) v = fmaf(v, g.scale[n], g.shift[n]);
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+    if (g.addrow) v += g.addrow[(size_t)m * g.ldr + n];
+    float* dst = g.C + (size_t)m * g.ldc + n;
+    *dst = g.accumulate ? *dst + v : v;
   }
 }
 
@@ -262,6 +300,154 @@ bn1d_relu_bwd_kernel(const float* __restrict__ ga1, int ld1, const float* __rest
   }
 }
 
+// Register-resident variants for M <= 16*R: block = 16 features x 16 row slices, every thread
+// loads its <= R rows ONCE (all loads in flight together), so the kernel costs one global round
+// trip instead of three dependent sweeps.
+__device__ inline float block_colsum16(float v, float (*red)[16], int sl, int cl) {
+  __syncthreads();
+  red[sl][cl] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][cl];
+  return s;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+bn1d_relu_fwd_reg_kernel(const float* __restrict__ y, int M, int N, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                         int64_t* __restrict__ nbt, float* __restrict__ ss, float* __restrict__ out, int ldo,
+                         const float* __restrict__ addrow, int ldr, int training) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, n = blockIdx.x * 16 + cl;
+  const bool ok = n < N;
+  float v[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = sl + 16 * i;
+    v[i] = (ok && m < M) ? y[(size_t)m * N + n] : 0.f;
+  }
+  float mean, rstd;
+  if (training) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) s += v[i];
+    mean = block_colsum16(s, red, sl, cl) / (float)M;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float d = (sl + 16 * i < M) ? v[i] - mean : 0.f;
+      q = fmaf(d, d, q);
+    }
+    const float m2 = block_colsum16(q, red, sl, cl);
+    const float var = m2 / (float)M;
+    rstd = 1.0f / sqrtf(var + BN1_EPS);
+    if (ok && sl == 0 && rmean) {
+      const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+      rmean[n] = (1.0f - BN1_MOMENTUM) * rmean[n] + BN1_MOMENTUM * mean;
+      rvar[n] = (1.0f - BN1_MOMENTUM) * rvar[n] + BN1_MOMENTUM * unbiased;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  } else {
+    mean = ok ? rmean[n] : 0.f;
+    rstd = ok ? 1.0f / sqrtf(rvar[n] + BN1_EPS) : 0.f;
+  }
+  if (!ok) return;
+  const float sc = gamma[n] * rstd, sh = beta[n] - mean * sc;
+  if (sl == 0) { ss[n] = sc; ss[N + n] = sh; ss[2 * N + n] = mean; ss[3 * N + n] = rstd; }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = sl + 16 * i;
+    if (m < M) {
+      float a = fmaxf(fmaf(v[i], sc, sh), 0.f);
+      if (addrow) a += addrow[(size_t)m * ldr + n];
+      out[(size_t)m * ldo + n] = a;
+    }
+  }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+bn1d_relu_bwd_reg_kernel(const float* __restrict__ ga1, int ld1, const float* __restrict__ ga2, int ld2,
+                         const float* __restrict__ y, int M, int N, const float* __restrict__ ss,
+                         const float* __restrict__ gamma, float* __restrict__ gy, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta, float* __restrict__ dbias, int training) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4, n = blockIdx.x * 16 + cl;
+  const bool ok = n < N;
+  float sc = 0.f, sh = 0.f, mean = 0.f, rstd = 0.f, gm = 0.f;
+  if (ok) { sc = ss[n]; sh = ss[N + n]; mean = ss[2 * N + n]; rstd = ss[3 * N + n]; gm = gamma[n]; }
+  float g[R], z[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = sl + 16 * i;
+    float yv = 0.f, gv = 0.f;
+    if (ok && m < M) {
+      yv = y[(size_t)m * N + n];
+      gv = ga1[(size_t)m * ld1 + n];
+      if (ga2) gv += ga2[(size_t)m * ld2 + n];
+    }
+    g[i] = fmaf(yv, sc, sh) > 0.f ? gv : 0.f;
+    z[i] = (yv - mean) * rstd;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    if (sl + 16 * i < M) { s1 += g[i]; s2 = fmaf(g[i], z[i], s2); }
+  }
+  s1 = block_colsum16(s1, red, sl, cl);
+  s2 = block_colsum16(s2, red, sl, cl);
+  if (!ok) return;
+  if (sl == 0) {
+    dgamma[n] = s2;
+    dbeta[n] = s1;
+    dbias[n] = training ? 0.f : s1 * gm * rstd;
+  }
+  const float k1 = s1 / (float)M, k2 = s2 / (float)M, gr = gm * rstd;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = sl + 16 * i;
+    if (m < M) gy[(size_t)m * N + n] = training ? gr * (g[i] - k1 - z[i] * k2) : g[i] * gr;
+  }
+}
+
+int bn1d_relu_fwd(const float* y, int M, int N, const float* gamma, const float* beta, float* rmean, float* rvar,
+                  int64_t* nbt, float* ss, float* out, int ldo, const float* addrow, int ldr, int training,
+                  hipStream_t st) {
+#define TDX_BN1_FWD(R_)                                                                            \
+  bn1d_relu_fwd_reg_kernel<R_><<<cdiv(N, 16), 256, 0, st>>>(y, M, N, gamma, beta, rmean, rvar, nbt, ss, out, ldo, \
+                                                            addrow, ldr, training)
+  if (M <= 32) TDX_BN1_FWD(2);
+  else if (M <= 128) TDX_BN1_FWD(8);
+  else if (M <= 256) TDX_BN1_FWD(16);
+  else if (M <= 1024) TDX_BN1_FWD(64);
+  else
+    bn1d_relu_fwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(y, M, N, gamma, beta, rmean, rvar, nbt, ss, out, ldo, addrow,
+                                                      ldr, training);
+#undef TDX_BN1_FWD
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int bn1d_relu_bwd(const float* ga1, int ld1, const float* ga2, int ld2, const float* y, int M, int N,
+                  const float* ss, const float* gamma, float* gy, float* dgamma, float* dbeta, float* dbias,
+                  int training, hipStream_t st) {
+#define TDX_BN1_BWD(R_)                                                                             \
+  bn1d_relu_bwd_reg_kernel<R_><<<cdiv(N, 16), 256, 0, st>>>(ga1, ld1, ga2, ld2, y, M, N, ss, gamma, gy, dgamma, \
+                                                            dbeta, dbias, training)
+  if (M <= 32) TDX_BN1_BWD(2);
+  else if (M <= 128) TDX_BN1_BWD(8);
+  else if (M <= 256) TDX_BN1_BWD(16);
+  else if (M <= 1024) TDX_BN1_BWD(64);
+  else
+    bn1d_relu_bwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(ga1, ld1, ga2, ld2, y, M, N, ss, gamma, gy, dgamma, dbeta,
+                                                      dbias, training);
+#undef TDX_BN1_BWD
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 // z = mu + eps * exp(0.5 * logvar)   (vae.py:55-58)
 __global__ void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                                const float* __restrict__ eps, float* __restrict__ z, int64_t n) {
@@ -401,11 +587,9 @@ int tdx_latent_forward(const float* const* P, void* const* buffers, const float*
       continue;
     }
     RC(linear_fwd(ws + in[u].off, in[u].ld, w, bias, ws + L.Y[u], N, B, N, K, 0, nullptr, nullptr, nullptr, 0, st));
-    bn1d_relu_fwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(
-        ws + L.Y[u], B, N, P[TDX_P_UNIT0 + 4 * u + 2], P[TDX_P_UNIT0 + 4 * u + 3], (float*)buffers[3 * u],
-        (float*)buffers[3 * u + 1], (int64_t*)buffers[3 * u + 2], ws + L.ss[u], ws + o[u].off, o[u].ld, addrow,
-        ldr, training);
-    TDX_CHECK_LAUNCH();
+    RC(bn1d_relu_fwd(ws + L.Y[u], B, N, P[TDX_P_UNIT0 + 4 * u + 2], P[TDX_P_UNIT0 + 4 * u + 3],
+                     (float*)buffers[3 * u], (float*)buffers[3 * u + 1], (int64_t*)buffers[3 * u + 2], ws + L.ss[u],
+                     ws + o[u].off, o[u].ld, addrow, ldr, training, st));
   }
   return linear_fwd(ws + o[12].off, 512, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, LATENT, B, LATENT, 512, 0, nullptr,
                     nullptr, nullptr, 0, st);
@@ -445,10 +629,8 @@ int tdx_latent_backward(const float* const* P, float* const* G, const float* d_o
     } else if (s <= 13) {
       const int u = 13 - s, K = LU[u].cin, N = LU[u].cout;
       const int pi = TDX_P_UNIT0 + 4 * u;
-      bn1d_relu_bwd_kernel<<<cdiv(N, 32), 256, 0, st>>>(
-          ws + gs[u].off, gs[u].ld, gs[u].off2 >= 0 ? ws + gs[u].off2 : nullptr, gs[u].ld2, ws + L.Y[u], B, N,
-          ws + L.ss[u], P[pi + 2], gY, G[pi + 2], G[pi + 3], G[pi + 1], training);
-      TDX_CHECK_LAUNCH();
+      RC(bn1d_relu_bwd(ws + gs[u].off, gs[u].ld, gs[u].off2 >= 0 ? ws + gs[u].off2 : nullptr, gs[u].ld2,
+                       ws + L.Y[u], B, N, ws + L.ss[u], P[pi + 2], gY, G[pi + 2], G[pi + 3], G[pi + 1], training, st));
       RC(linear_wgrad(gY, N, ws + in[u].off, in[u].ld, G[pi], B, N, K, st));
       const Route gi = gin(u);
       RC(linear_dgrad(gY, N, P[pi], ws + gi.off, gi.ld, B, N, K, 0, st));
