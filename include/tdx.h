@@ -77,6 +77,9 @@ int tdx_p_sample_step(float* x_out, const float* x, const float* eps, const floa
 int tdx_p_sample_step_philox(float* x_out, const float* x, const float* eps,
                              const float* coef, const int32_t* t_idx, int64_t n,
                              uint64_t seed, tdx_stream_t stream);
+/* Device-side step counter for graph-captured sampling loops: t = *counter; *t_idx = t;
+ * t_vec[0..n) = t; *counter = t - 1.  (diffusion.py:259-260 rebuilds t on the host per step.) */
+int tdx_step_begin(int64_t* counter, int32_t* t_idx, int64_t* t_vec, int n, tdx_stream_t stream);
 
 /* Caller side of the path: minibatch gather from a device-resident uint8
  * dataset fused with ToTensor + Normalize((mean,),(std,)) of diffusion.py:202-204:

@@ -55,6 +55,32 @@ def _stamp_matches():
         return False
 
 
+STAMP = LIB + ".src_sha256"
+
+
+def source_hash() -> str:
+    """SHA-256 over every HIP source / header and the compiler flags: written next to the
+    library by build(); a differing stamp means the .so was built from other sources (file
+    times are not comparable across machines, contents are)."""
+    import hashlib
+
+    h = hashlib.sha256(_flags_stamp().encode())
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "tdx.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stamp_mismatch() -> bool:
+    """True only when a stamp exists and disagrees with the current sources."""
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return False
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -66,7 +92,7 @@ def is_stale():
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every csrc/*.hip for gfx950 and link libtdx.so next to this file."""
-    if not force and not is_stale():
+    if not force and not is_stale() and not stamp_mismatch():
         return LIB
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
@@ -99,6 +125,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.replace(tmp, LIB)
     with open(os.path.join(OBJDIR, "flags.txt"), "w") as f:
         f.write(_flags_stamp())
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
 
 

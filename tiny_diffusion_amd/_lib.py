@@ -32,6 +32,8 @@ def _load():
                 "(there is no CPU fallback for the HIP path)"
             )
         _build.build()
+    elif _build.stamp_mismatch() and not os.environ.get("TDX_NO_AUTOBUILD"):
+        _build.build(force=False)  # the sources changed since the library was linked
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     # one HIP runtime per process, or streams/pointers would not be shared
     hips = set()
@@ -85,6 +87,7 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_bilinear_ac_bwd": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _ptr]),
+    "tdx_step_begin": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, _ptr]),
     "tdx_linear_fwd": (C.c_int, [_ptr, C.c_int, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_linear_bwd": (C.c_int, [_ptr, C.c_int, _ptr, C.c_int, _ptr, _ptr, C.c_int, _ptr, _ptr, C.c_int, C.c_int,
                                  C.c_int, _ptr]),

@@ -94,14 +94,23 @@ extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_r
 }
 
 // ------------------------------------------------------------------ backward
-#define BWD_ROWS 512  // rows per block in the reduction pass
+// Rows per block of the reduction pass: sized so that the grid has ~2048 workgroups whatever the
+// layer (the deep layers have few rows but many channels; a fixed 512 rows per block left
+// them with 8..98 workgroups on 256 CUs and the pass ran at a fraction of HBM speed).
+static int bwd_rows_per_block(int64_t rows, int C) {
+  const int rgroups = 256 / (C / 4);
+  int64_t rpb = (rows + 2047) / 2048;
+  if (rpb < 2 * rgroups) rpb = 2 * rgroups;
+  if (rpb > 512) rpb = 512;
+  return (int)((rpb + rgroups - 1) / rgroups * rgroups);
+}
 
 // partial[blk][2][C]: sum gz, sum gz*xhat over the block's rows
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t rows, int C,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                     float* __restrict__ partial) {
+                     float* __restrict__ partial, int rpb) {
   extern __shared__ float red[];  // [rgroups][2][C]
   const int c4n = C / 4;
   const int col = threadIdx.x % c4n, rg = threadIdx.x / c4n, rgroups = 256 / c4n;
@@ -111,8 +120,9 @@ bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y, i
   const float4 mu = *reinterpret_cast<const float4*>(mean + c);
   const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  const int64_t r0 = (int64_t)blockIdx.x * BWD_ROWS;
-  const int64_t r1 = min(r0 + BWD_ROWS, rows);
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = min(r0 + rpb, rows);
+#pragma unroll 4
   for (int64_t r = r0 + rg; r < r1; r += rgroups) {
     const float4 gv = *reinterpret_cast<const float4*>(g + r * C + c);
     const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
@@ -142,21 +152,23 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count
                        const float* __restrict__ scale, float* __restrict__ dgamma,
                        float* __restrict__ dbeta, float* __restrict__ dbias,
                        float* __restrict__ coef, int training) {
-  __shared__ double red[2][8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int t = sl; t < nblk; t += 8) {
+  if (c < C) {
+#pragma unroll 8
+    for (int t = sl; t < nblk; t += 16) {
       s1 += (double)partial[((size_t)t * 2 + 0) * C + c];
       s2 += (double)partial[((size_t)t * 2 + 1) * C + c];
     }
+  }
   red[0][sl][cl] = s1;
   red[1][sl][cl] = s2;
   __syncthreads();
   if (sl == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
-    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    for (int k = 0; k < 16; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     if (training) {
@@ -205,7 +217,8 @@ bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t 
 }
 
 extern "C" size_t tdx_bn_relu_bwd_scratch_floats(int64_t rows, int C) {
-  return (size_t)cdiv(rows, BWD_ROWS) * 2 * C + 3 * (size_t)C;
+  if (rows <= 0 || C <= 0 || C % 4 || C > 1024 || (256 % (C / 4)) != 0) return 0;
+  return (size_t)cdiv(rows, bwd_rows_per_block(rows, C)) * 2 * C + 3 * (size_t)C;
 }
 
 extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, const float* scale,
@@ -216,14 +229,15 @@ extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, co
     return TDX_E_BADARG;
   if (C % 4 || C > 1024 || (256 % (C / 4)) != 0) return TDX_E_SHAPE;
   hipStream_t st = to_stream(stream);
-  const int nblk = cdiv(rows, BWD_ROWS);
+  const int rpb = bwd_rows_per_block(rows, C);
+  const int nblk = cdiv(rows, rpb);
   float* partial = scratch;
   float* coef = scratch + (size_t)nblk * 2 * C;
   const int rgroups = 256 / (C / 4);
   bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
-      g, y, rows, C, scale, shift, save_mean, save_rstd, partial);
+      g, y, rows, C, scale, shift, save_mean, save_rstd, partial, rpb);
   TDX_CHECK_LAUNCH();
-  bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
+  bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
                                                      save_rstd, scale, dgamma, dbeta, dbias, coef,
                                                      training);
   TDX_CHECK_LAUNCH();

@@ -90,7 +90,7 @@ __device__ static inline float p_step(float x, float e, float z, float c1, float
 }
 
 template <bool PHILOX>
-__global__ void p_sample_kernel(float4* __restrict__ xo, const float4* __restrict__ x,
+__global__ void p_sample_kernel(float4* xo, const float4* x,  // may alias: in-place update
                                 const float4* __restrict__ eps, const float4* __restrict__ z,
                                 const float* __restrict__ coef, const int32_t* __restrict__ t_idx,
                                 int64_t n4, uint64_t seed) {
@@ -131,6 +131,27 @@ extern "C" int tdx_p_sample_step_philox(float* x_out, const float* x, const floa
   if (n % 4) return TDX_E_SHAPE;
   p_sample_kernel<true><<<ew_grid(n / 4, 256), 256, 0, to_stream(stream)>>>(
       (float4*)x_out, (const float4*)x, (const float4*)eps, nullptr, coef, t_idx, n / 4, seed);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// Device-side step counter for graph-captured sampling: t = *counter; t_idx = t; t_vec[:] = t;
+// *counter = t - 1.  One block; lets a HIP graph hold several consecutive reverse steps with no
+// host work between them (diffusion.py:259-260 builds the same t tensor on the host each step).
+__global__ void step_begin_kernel(int64_t* __restrict__ counter, int32_t* __restrict__ t_idx,
+                                  int64_t* __restrict__ t_vec, int n) {
+  const int64_t t = *counter;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) t_vec[i] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *t_idx = (int32_t)t;
+    *counter = t - 1;
+  }
+}
+
+extern "C" int tdx_step_begin(int64_t* counter, int32_t* t_idx, int64_t* t_vec, int n, tdx_stream_t stream) {
+  if (!counter || !t_idx || !t_vec || n <= 0) return TDX_E_BADARG;
+  step_begin_kernel<<<1, 256, 0, to_stream(stream)>>>(counter, t_idx, t_vec, n);
   TDX_CHECK_LAUNCH();
   return 0;
 }

@@ -27,6 +27,15 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
                        hipStream_t st);
+#define TDX_PACK_MAX 13
+struct TdxPackBatch {
+  const float* w[TDX_PACK_MAX];
+  float* wf[TDX_PACK_MAX];
+  float* wd[TDX_PACK_MAX];
+  int cout[TDX_PACK_MAX], cin[TDX_PACK_MAX], cin_real[TDX_PACK_MAX], chunk_start[TDX_PACK_MAX];
+  int count;
+};
+int tdx_pack_conv3x3_batch(TdxPackBatch* b, tdx_stream_t stream);
 // conv3x3 weight packs / gradient for an input tensor zero-padded from cin_real to cin channels
 int tdx_pack_conv3x3_pad(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout, int cin_real,
                          int cin, tdx_stream_t stream);

@@ -266,11 +266,22 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     u->packed = buffers != nullptr;
     return 0;
   }
+  TdxPackBatch pb;
+  pb.count = 13;
   for (int i = 0; i < 13; ++i) {
     const UnitDef& d = u->spec->units[i];
-    int rc = tdx_pack_conv3x3_pad(P[TDX_P_UNIT0 + 4 * i], u->wpack + u->wf_off[i],
-                                  u->wpack + u->wd_off[i], d.cout, d.cin_real, d.cin, stream);
+    pb.w[i] = P[TDX_P_UNIT0 + 4 * i];
+    pb.wf[i] = u->wpack + u->wf_off[i];
+    pb.wd[i] = u->wpack + u->wd_off[i];
+    pb.cout[i] = d.cout; pb.cin[i] = d.cin; pb.cin_real[i] = d.cin_real;
+  }
+  {
+    int rc = tdx_pack_conv3x3_batch(&pb, stream);
     if (rc) return rc;
+  }
+  for (int i = 0; i < 13; ++i) {
+    const UnitDef& d = u->spec->units[i];
+    int rc = 0;
     if (buffers) {
       float* ss = u->infer_ss + u->iss_off[i];
       rc = tdx_bn_finalize(nullptr, 0, 0, 0, d.cout, P[TDX_P_UNIT0 + 4 * i + 2],

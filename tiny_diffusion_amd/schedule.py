@@ -11,6 +11,9 @@ from . import _lib
 from ._lib import lib, check
 
 
+GRAPH_STEPS = 10  # reverse steps per captured graph in the device-counter mode
+
+
 class ForwardProcess:
     """diffusion.py:165-190.  ``betas`` / ``alphas`` / ``alphas_cumprod`` are CPU
     fp32 tensors computed with the reference's expressions (bit-identical); device
@@ -104,7 +107,9 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
     ``noises``: mapping/sequence t -> z (recorded noise, parity tests).
     ``philox_seed``: in-kernel noise, no z tensor at all (throughput mode).
     ``use_graph``: capture one reverse step (UNet forward + update) into a HIP graph
-    and replay it T times; the step index lives in device memory.
+    and replay it T times; the step index lives in device memory.  Together with
+    ``philox_seed`` the index is also advanced on the device and each graph holds
+    ``GRAPH_STEPS`` consecutive steps (no host work between steps).
     """
     device = torch.device(device)
     if device.type != "cuda":
@@ -119,33 +124,66 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
     t_idx = torch.empty(1, dtype=torch.int32, device=device)
     t_vec = torch.empty(n_samples, dtype=torch.int64, device=device)
     st = lambda: torch.cuda.current_stream(device).cuda_stream  # noqa: E731
-    x_next = torch.empty_like(x)
     zbuf = torch.empty_like(x)
 
     def step_kernels(use_z: bool):
         eps = noise_model._run_forward(x, t_vec, y, mode=2)[0]
+        # the update is elementwise: x is overwritten in place
         if philox_seed is not None:
-            check(lib.tdx_p_sample_step_philox(x_next.data_ptr(), x.data_ptr(), eps.data_ptr(), coef.data_ptr(),
+            check(lib.tdx_p_sample_step_philox(x.data_ptr(), x.data_ptr(), eps.data_ptr(), coef.data_ptr(),
                                                t_idx.data_ptr(), x.numel(), philox_seed, st()), "tdx_p_sample_step")
         else:
-            check(lib.tdx_p_sample_step(x_next.data_ptr(), x.data_ptr(), eps.data_ptr(),
+            check(lib.tdx_p_sample_step(x.data_ptr(), x.data_ptr(), eps.data_ptr(),
                                         zbuf.data_ptr() if use_z else None, coef.data_ptr(), t_idx.data_ptr(),
                                         x.numel(), st()), "tdx_p_sample_step")
-        x.copy_(x_next)
 
-    graph = None
-    if use_graph:
-        t_idx.fill_(T - 1); t_vec.fill_(T - 1)
+    def capture(fn):
+        """Warm up once on a side stream (first-launch attribute calls, packing), restore x,
+        then capture ``fn`` into a HIP graph."""
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         x_keep = x.clone()
         with torch.cuda.stream(side):
-            step_kernels(True)          # warm-up: first-launch attribute calls, packing
+            fn()
         torch.cuda.current_stream(device).wait_stream(side)
         x.copy_(x_keep)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step_kernels(True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    if use_graph and philox_seed is not None:
+        # No per-step input from the host at all: the step index lives in device memory and is
+        # advanced by a kernel, so one graph holds several consecutive reverse steps.
+        counter = torch.empty(1, dtype=torch.int64, device=device)
+
+        def steps(k):
+            def run():
+                for _ in range(k):
+                    check(lib.tdx_step_begin(counter.data_ptr(), t_idx.data_ptr(), t_vec.data_ptr(), n_samples, st()),
+                          "tdx_step_begin")
+                    step_kernels(False)
+            return run
+
+        unroll = min(GRAPH_STEPS, T)
+        counter.fill_(T - 1)
+        graph = capture(steps(unroll))
+        tail = T % unroll
+        tail_graph = None
+        if tail:
+            counter.fill_(T - 1)
+            tail_graph = capture(steps(tail))
+        counter.fill_(T - 1)
+        for _ in range(T // unroll):
+            graph.replay()
+        if tail_graph is not None:
+            tail_graph.replay()
+        return x
+
+    graph = None
+    if use_graph:
+        t_idx.fill_(T - 1); t_vec.fill_(T - 1)
+        graph = capture(lambda: step_kernels(True))
     for t in reversed(range(T)):
         t_idx.fill_(t)
         t_vec.fill_(t)
