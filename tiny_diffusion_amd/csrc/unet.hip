@@ -67,7 +67,7 @@ struct Layout {
   size_t ep[3], cat[3], d1a;    // pooled encoder outputs, decoder inputs (cat[0] = level 3), resized d1
   size_t stats;                 // conv epilogue partials (largest unit)
   // backward
-  size_t G1, G2, GS[3], gtp[3], slabs, bnscr, smallp, timescr;
+  size_t G1, G2, GS[3], gtp[3], slabs, bnscr, smallp, smallp2, timescr;
   size_t gbuf;                  // floats in EACH of G1, G2
   size_t total;
 };
@@ -113,6 +113,7 @@ Layout make_layout(const NetSpec& S, int B) {
   L.slabs = take(slabs);
   L.bnscr = take(bnscr);
   L.smallp = take((size_t)tdx_small_conv_wgrad_blocks(B, S.hw0, S.hw0) * tdx_small_conv_partial_width());
+  L.smallp2 = take((size_t)tdx_small_conv_wgrad_blocks(B, S.hw0, S.hw0) * tdx_small_conv_partial_width());
   L.timescr = take(3 * b * S.time_dim);
   L.total = o;
   return L;
@@ -133,7 +134,7 @@ struct tdx_unet {
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
   hipStream_t side;
-  hipEvent_t ev_dy[13], ev_w[13], ev_join;
+  hipEvent_t ev_dy[13], ev_w[13], ev_join, ev_fork, ev_pack;
 };
 
 extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes) {
@@ -174,6 +175,8 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
     (void)hipEventCreateWithFlags(&u->ev_w[i], hipEventDisableTiming);
   }
   (void)hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&u->ev_pack, hipEventDisableTiming);
   *out = u;
   return 0;
 }
@@ -190,6 +193,8 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
     (void)hipEventDestroy(u->ev_w[i]);
   }
   (void)hipEventDestroy(u->ev_join);
+  (void)hipEventDestroy(u->ev_fork);
+  (void)hipEventDestroy(u->ev_pack);
   (void)hipStreamDestroy(u->side);
   (void)hipFree(u->wpack);
   (void)hipFree(u->infer_ss);
@@ -255,8 +260,11 @@ extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, s
 
 // weights always; the INFER-mode scale/shift (from the running statistics) only when
 // `buffers` is given
+// `overlap`: the packs of units 2..12 (98 % of the weights) are written on the side stream while
+// the main stream runs the time path, initial_conv and the first two units; the caller makes the
+// main stream wait for ev_pack before unit 2.
 static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffers,
-                     tdx_stream_t stream) {
+                     tdx_stream_t stream, bool overlap = false) {
   const float* const* P = reinterpret_cast<const float* const*>(params);
   if (!u->spec) {
     if (buffers) {
@@ -275,7 +283,23 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     pb.wd[i] = u->wpack + u->wd_off[i];
     pb.cout[i] = d.cout; pb.cin[i] = d.cin; pb.cin_real[i] = d.cin_real;
   }
-  {
+  if (overlap) {
+    TdxPackBatch head = pb, tail = pb;
+    head.count = 2;
+    tail.count = 11;
+    for (int i = 0; i < 11; ++i) {
+      tail.w[i] = pb.w[i + 2]; tail.wf[i] = pb.wf[i + 2]; tail.wd[i] = pb.wd[i + 2];
+      tail.cout[i] = pb.cout[i + 2]; tail.cin[i] = pb.cin[i + 2]; tail.cin_real[i] = pb.cin_real[i + 2];
+    }
+    hipStream_t st = to_stream(stream);
+    TDX_HIP(hipEventRecord(u->ev_fork, st));            // the parameters are final on the main stream
+    TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+    int rc = tdx_pack_conv3x3_batch(&tail, reinterpret_cast<tdx_stream_t>(u->side));
+    if (rc) return rc;
+    TDX_HIP(hipEventRecord(u->ev_pack, u->side));
+    rc = tdx_pack_conv3x3_batch(&head, stream);
+    if (rc) return rc;
+  } else {
     int rc = tdx_pack_conv3x3_batch(&pb, stream);
     if (rc) return rc;
   }
@@ -342,7 +366,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const int64_t* labels = u->kind == 0 ? static_cast<const int64_t*>(cond) : nullptr;
   const float* cond_emb = u->kind == 1 ? static_cast<const float*>(cond) : nullptr;
 
-  if (!infer) RC(pack_impl(u, params, nullptr, stream));  // weights change every step
+  if (!infer) RC(pack_impl(u, params, nullptr, stream, true));  // weights change every step
   else if (!u->packed) RC(pack_impl(u, params, buffers, stream));
   if (!infer) {
     // keep the inputs for backward (caller tensors may be gone by then)
@@ -391,6 +415,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   RC(run_unit(0, ws + L.x0));
   for (int k = 0; k < 3; ++k) {
     const int ua = 2 * k, ub = 2 * k + 1;
+    if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
     if (k > 0) RC(run_unit(ua, ws + L.ep[k - 1]));
     RC(run_unit(ub, ws + L.Y[ua]));
     RC(tdx_maxpool2_ceil_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
@@ -485,10 +510,12 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     const float* ish = d.in_bn ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
     RC(tdx_conv3x3_wgrad(in, g, ws + L.slabs, B, d.hw, d.hw, d.cin, d.cout,
                          d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish, side));
+    // dy is free again once the wgrad GEMM has read it; the slab reduction that follows only
+    // touches side-stream buffers and is covered by the join at the end of the call
+    TDX_HIP(hipEventRecord(u->ev_w[i], u->side));
     RC(tdx_conv3x3_wgrad_reduce_pad(ws + L.slabs, G[TDX_P_UNIT0 + 4 * i],
                                     tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
                                     d.cin_real, side));
-    TDX_HIP(hipEventRecord(u->ev_w[i], u->side));
     // main: input gradient = the forward kernel on the flipped pack, channels swapped.
     // It writes the OTHER ping-pong buffer, whose previous dy reader must be done.
     RC(wait_wgrad());
@@ -529,9 +556,11 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
 
   for (int s = stage_lo; s < stage_hi; ++s) {
     switch (s) {
-      case 0:  // final_conv + the output resize
-        RC(tdx_final_conv_wgrad(ws + L.d1a, d_out, ws + L.smallp, G[TDX_P_FINAL_W], G[TDX_P_FINAL_B], B,
-                                S.out_hw, S.out_hw, S.in_ch, st));
+      case 0:  // final_conv + the output resize; its weight gradient is off the critical path
+        TDX_HIP(hipEventRecord(u->ev_fork, st));  // d_out is ready on the main stream
+        TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+        RC(tdx_final_conv_wgrad(ws + L.d1a, d_out, ws + L.smallp2, G[TDX_P_FINAL_W], G[TDX_P_FINAL_B], B,
+                                S.out_hw, S.out_hw, S.in_ch, u->side));
         RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], G1, B, S.out_hw, S.out_hw, S.in_ch, st));
         RC(tdx_bilinear_ac_bwd(G1, G2, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
         break;
@@ -549,12 +578,15 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 12: RC(unit_bwd(1, ws + L.Y[0])); break;
       case 13: RC(unit_bwd(0, ws + L.x0)); break;  // g(x0) lands in G1
       case 14:
+        // the time / class path only needs the three pixel sums: side stream, beside initial_conv
+        TDX_HIP(hipEventRecord(u->ev_fork, st));
+        TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
         RC(tdx_initial_conv_wgrad(ws + L.x, G1, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
                                   S.hw0, S.in_ch, S.x0_real, st));
         RC(tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
                               u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
                               P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, st));
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side));
         break;
     }
   }
