@@ -279,6 +279,12 @@ int tdx_unet_backward_stages(void);
 int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads,
                       const float* d_out, void* workspace, size_t workspace_bytes,
                       int batch, int stage_lo, int stage_hi, tdx_stream_t stream);
+/* A call that ends before the last stage does not make `stream` wait for the library's internal
+ * streams (weight-gradient GEMMs, skip-branch resizes).  This orders `stream` - typically the
+ * stream of the gradient all-reduce - after everything enqueued so far by tdx_unet_backward,
+ * so that the gradients of the finished stages are final there.  (The caller orders `stream`
+ * after its own compute stream as well.) */
+int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream);
 
 /* Testing aid: offset (in floats) and element count of a named intermediate inside the
  * workspace after a forward: "x0", "Y0".."Y12", "ss0".."ss12", "e1p", "cat1", "d1a", ... */

@@ -352,3 +352,41 @@ def test_train_step_matches_module_plus_torch_adam(cond):
                 assert (diff > 1e-5).float().mean().item() <= 2e-3, (k, (diff > 1e-5).float().mean().item())
     for (k, a), (_, b) in zip(m.named_buffers(), ref.named_buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), k
+
+
+def test_staged_backward_equals_single_call():
+    """tdx_unet_backward over split stage ranges (the bucketed all-reduce path) - with the
+    explicit tdx_unet_backward_join on another stream - gives bit-identical gradients to one
+    call over all stages."""
+    from tiny_diffusion_amd._lib import lib, check
+
+    m = build(True, 4)
+    m.train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 1, 28, 28, generator=g).cuda()
+    t = torch.randint(0, 1000, (6,), generator=g).cuda()
+    y = torch.randint(0, 10, (6,), generator=g).cuda()
+    d_out = torch.randn(6, 1, 28, 28, generator=g).cuda()
+    _, views = m._grad_buffers(x.device)
+    flat = m._grad_flat
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    _, plan, _ = m._run_forward(x, t, y, mode=0)
+    m._run_backward(plan, d_out, views)
+    torch.cuda.synchronize()
+    want = flat.clone()
+    m.load_state_dict(sd)  # same BN buffers for the second forward
+    flat.zero_()
+    _, plan, _ = m._run_forward(x, t, y, mode=0)
+    comm = torch.cuda.Stream()
+    for lo, hi in ((0, 5), (5, 6), (6, 11), (11, 15)):
+        m._run_backward(plan, d_out, views, lo, hi)
+        comm.wait_stream(torch.cuda.current_stream())
+        check(lib.tdx_unet_backward_join(plan.handle, comm.cuda_stream), "join")
+    torch.cuda.current_stream().wait_stream(comm)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)
+    # stages out of order / without a forward are refused
+    with pytest.raises(Exception):
+        m2 = build(False, 4)
+        _, plan2, _ = m2._run_forward(x, t, None, mode=2)
+        m2._run_backward(plan2, d_out, m2._grad_buffers(x.device)[1], 3, 5)

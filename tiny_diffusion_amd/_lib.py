@@ -104,6 +104,7 @@ _SIGS = {
     "tdx_unet_backward_stages": (C.c_int, []),
     "tdx_unet_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     _ptr]),
+    "tdx_unet_backward_join": (C.c_int, [_ptr, _ptr]),
     "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
     "tdx_unet_tensor": (C.c_int, [_ptr, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tdx_tune_set": (C.c_int, [C.c_char_p, C.c_int]),

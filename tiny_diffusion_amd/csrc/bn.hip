@@ -14,16 +14,17 @@
 //     M2 = sum_t M2_t + sum_t S_t^2 / n_t - S^2 / N ,   S = sum_t S_t
 // The last two terms cancel, but they are accumulated in double: with |mean|/std up to 1e4 that
 // still leaves 8 significant digits, while the fp32-sensitive part (deviations inside a tile)
-// was centred before it was ever summed.  block = 16 channels x 16 interleaved tile slices.
+// was centred before it was ever summed.  block = 4 channels x 64 interleaved tile slices
+// (many small blocks: the kernel sits on the critical path between two convolutions).
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t count, int C,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* __restrict__ rmean, float* __restrict__ rvar,
                    int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ save_mean, float* __restrict__ save_rstd, int training) {
-  __shared__ double red[3][16][16];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[3][64][4];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   if (training) {
     double S = 0.0, Q = 0.0, R = 0.0;
     if (c < C) {
@@ -31,7 +32,7 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, in
       const int64_t last_rows = count - (int64_t)(tiles - 1) * tile_rows;
       const double inv_last = 1.0 / (double)last_rows;
 #pragma unroll 4
-      for (int t = sl; t < tiles; t += 16) {
+      for (int t = sl; t < tiles; t += 64) {
         const double st = (double)stats[((size_t)t * 2 + 0) * C + c];
         const double qt = (double)stats[((size_t)t * 2 + 1) * C + c];
         S += st;
@@ -46,7 +47,7 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, in
     if (sl == 0 && c < C) {
       S = 0.0; Q = 0.0; R = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; R += red[2][k][cl]; }
+      for (int k = 0; k < 64; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; R += red[2][k][cl]; }
       const double n = (double)count;
       const double mean = S / n;
       double m2 = Q + (R - S * S / n);
@@ -86,7 +87,7 @@ extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_r
   if (training && ((int64_t)tiles * tile_rows < count || (int64_t)(tiles - 1) * tile_rows >= count))
     return TDX_E_BADARG;
   if (!training && (!running_mean || !running_var)) return TDX_E_BADARG;
-  bn_finalize_kernel<<<cdiv(C, 16), 256, 0, to_stream(stream)>>>(
+  bn_finalize_kernel<<<cdiv(C, 4), 256, 0, to_stream(stream)>>>(
       stats_partial, tiles, tile_rows, count, C, gamma, beta, running_mean, running_var,
       num_batches_tracked, scale, shift, save_mean, save_rstd, training);
   TDX_CHECK_LAUNCH();
@@ -152,13 +153,13 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count
                        const float* __restrict__ scale, float* __restrict__ dgamma,
                        float* __restrict__ dbeta, float* __restrict__ dbias,
                        float* __restrict__ coef, int training) {
-  __shared__ double red[2][16][16];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
 #pragma unroll 8
-    for (int t = sl; t < nblk; t += 16) {
+    for (int t = sl; t < nblk; t += 64) {
       s1 += (double)partial[((size_t)t * 2 + 0) * C + c];
       s2 += (double)partial[((size_t)t * 2 + 1) * C + c];
     }
@@ -168,7 +169,7 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count
   __syncthreads();
   if (sl == 0 && c < C) {
     s1 = 0.0; s2 = 0.0;
-    for (int k = 0; k < 16; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    for (int k = 0; k < 64; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     if (training) {
@@ -237,7 +238,7 @@ extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, co
   bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
       g, y, rows, C, scale, shift, save_mean, save_rstd, partial, rpb);
   TDX_CHECK_LAUNCH();
-  bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
+  bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
                                                      save_rstd, scale, dgamma, dbeta, dbias, coef,
                                                      training);
   TDX_CHECK_LAUNCH();

@@ -67,8 +67,8 @@ struct Layout {
   size_t ep[3], cat[3], d1a;    // pooled encoder outputs, decoder inputs (cat[0] = level 3), resized d1
   size_t stats;                 // conv epilogue partials (largest unit)
   // backward
-  size_t G1, G2, GS[3], gtp[3], slabs, bnscr, smallp, smallp2, timescr;
-  size_t gbuf;                  // floats in EACH of G1, G2
+  size_t G1, G2, G3, G4, GS[3], gtp[3], slabs, bnscr, smallp, smallp2, timescr;
+  size_t gbuf;                  // floats in EACH of G1..G4
   size_t total;
 };
 
@@ -105,7 +105,7 @@ Layout make_layout(const NetSpec& S, int B) {
   gbuf = std::max(gbuf, b * (size_t)S.out_hw * S.out_hw * 64);
   L.stats = take(stats);
   L.gbuf = gbuf;
-  L.G1 = take(gbuf); L.G2 = take(gbuf);
+  L.G1 = take(gbuf); L.G2 = take(gbuf); L.G3 = take(gbuf); L.G4 = take(gbuf);
   for (int k = 0; k < 3; ++k) {
     L.GS[k] = take(b * S.enc_hw[k] * S.enc_hw[k] * S.skip_ch[k]);
     L.gtp[k] = take(b * S.skip_ch[k]);
@@ -130,11 +130,19 @@ struct tdx_unet {
   size_t iss_off[13];
   bool packed;
   int saved_batch, saved_mode;  // state of the last forward (for backward)
+  // backward state that survives between tdx_unet_backward calls that split the stages:
+  float* g_next;                // where the gradient w.r.t. the next unit's activation lives
+  struct GBuf { float* p; int w_unit; int s2; int age; } gb[4];  // rotating gradient buffers + last readers
+  int clock;
   // backward runs the weight-gradient GEMMs on a second (low-priority) HIP stream so that
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
   hipStream_t side;
   hipEvent_t ev_dy[13], ev_w[13], ev_join, ev_fork, ev_pack;
+  // third stream: the HBM-bound skip-branch resizes (forward and backward) run beside the
+  // convolutions instead of between them
+  hipStream_t side2;
+  hipEvent_t ev_s2_fork[3], ev_s2_done[3], ev_join2;
 };
 
 extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes) {
@@ -166,6 +174,7 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   u->packed = false;
   u->saved_batch = 0;
   u->saved_mode = -1;
+  u->g_next = nullptr;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
   e = hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, lo);
@@ -177,6 +186,13 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   (void)hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_pack, hipEventDisableTiming);
+  e = hipStreamCreateWithFlags(&u->side2, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  for (int i = 0; i < 3; ++i) {
+    (void)hipEventCreateWithFlags(&u->ev_s2_fork[i], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&u->ev_s2_done[i], hipEventDisableTiming);
+  }
+  (void)hipEventCreateWithFlags(&u->ev_join2, hipEventDisableTiming);
   *out = u;
   return 0;
 }
@@ -195,6 +211,13 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
   (void)hipEventDestroy(u->ev_join);
   (void)hipEventDestroy(u->ev_fork);
   (void)hipEventDestroy(u->ev_pack);
+  (void)hipStreamSynchronize(u->side2);
+  for (int i = 0; i < 3; ++i) {
+    (void)hipEventDestroy(u->ev_s2_fork[i]);
+    (void)hipEventDestroy(u->ev_s2_done[i]);
+  }
+  (void)hipEventDestroy(u->ev_join2);
+  (void)hipStreamDestroy(u->side2);
   (void)hipStreamDestroy(u->side);
   (void)hipFree(u->wpack);
   (void)hipFree(u->infer_ss);
@@ -239,7 +262,7 @@ extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, s
       {"cat1", L.cat[2], b * sq(S.units[11].hw) * S.units[11].cin},
       {"d1a", L.d1a, b * sq(S.out_hw) * 64}, {"emb", L.emb, b * S.time_dim},
       {"t1", L.tp[0], b * S.skip_ch[0]}, {"t2", L.tp[1], b * S.skip_ch[1]}, {"t3", L.tp[2], b * S.skip_ch[2]},
-      {"G1", L.G1, L.gbuf}, {"G2", L.G2, L.gbuf},
+      {"G1", L.G1, L.gbuf}, {"G2", L.G2, L.gbuf}, {"G3", L.G3, L.gbuf}, {"G4", L.G4, L.gbuf},
       {"GS1", L.GS[0], b * sq(S.enc_hw[0]) * S.skip_ch[0]},
       {"GS2", L.GS[1], b * sq(S.enc_hw[1]) * S.skip_ch[1]},
       {"GS3", L.GS[2], b * sq(S.enc_hw[2]) * S.skip_ch[2]}};
@@ -418,6 +441,19 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
     if (k > 0) RC(run_unit(ua, ws + L.ep[k - 1]));
     RC(run_unit(ub, ws + L.Y[ua]));
+    if (!infer) {
+      // the skip branch resize(e_k + t_k) -> second half of the decoder's concat buffer only needs
+      // this unit: do it now on the third stream, beside the rest of the encoder
+      const int kd = 2 - k, ud = 7 + 2 * kd;  // decoder level / its first unit
+      const UnitDef& dd = S.units[ud];
+      const int c_up = S.units[kd == 0 ? 6 : 6 + 2 * kd].cout;
+      TDX_HIP(hipEventRecord(u->ev_s2_fork[k], st));
+      TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_s2_fork[k], 0));
+      RC(tdx_bilinear_ac_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.tp[k], ws + L.cat[kd], B, S.enc_hw[k],
+                             S.enc_hw[k], dd.hw, dd.hw, S.skip_ch[k], dd.cin, c_up,
+                             reinterpret_cast<tdx_stream_t>(u->side2)));
+      TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
+    }
     RC(tdx_maxpool2_ceil_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
                              S.skip_ch[k], stream));
   }
@@ -433,8 +469,11 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const int hw = da.hw, c_up = dp.cout, c_skip = S.skip_ch[skip_k];
     RC(tdx_bilinear_ac_fwd(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
                            c_up, da.cin, 0, stream));
-    RC(tdx_bilinear_ac_fwd(ws + L.Y[skip_u], sc(skip_u), sh(skip_u), ws + L.tp[skip_k], ws + L.cat[k], B,
-                           S.enc_hw[skip_k], S.enc_hw[skip_k], hw, hw, c_skip, da.cin, c_up, stream));
+    if (infer)
+      RC(tdx_bilinear_ac_fwd(ws + L.Y[skip_u], sc(skip_u), sh(skip_u), ws + L.tp[skip_k], ws + L.cat[k], B,
+                             S.enc_hw[skip_k], S.enc_hw[skip_k], hw, hw, c_skip, da.cin, c_up, stream));
+    else
+      TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[skip_k], 0));  // written during the encoder
     RC(run_unit(ua, ws + L.cat[k]));
     RC(run_unit(ub, ws + L.Y[ua]));
   }
@@ -470,32 +509,52 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   hipStream_t st = to_stream(stream);
   const int B = batch;
   const int training = u->saved_mode == TDX_MODE_TRAIN ? 1 : 0;
-  float* G1 = ws + L.G1;
-  float* G2 = ws + L.G2;
-
-  // Gradient buffers alternate between G1 and G2 in a fixed pattern; `g_of[u]` is where the
-  // gradient w.r.t. unit u's activation lives when its stage starts.
-  // unit:            0   1   2   3   4   5   6   7   8   9   10  11  12
-  float* g_of[13] = {G2, G1, G1, G2, G2, G1, G1, G1, G2, G2, G1, G1, G2};
-  auto other = [&](float* g) { return g == G1 ? G2 : G1; };
-
-  tdx_stream_t side = reinterpret_cast<tdx_stream_t>(u->side);
-  int pending_w = -1;  // unit whose wgrad (side stream) still reads its dy buffer
-  // Every kernel on the main stream that OVERWRITES the buffer holding dy of `pending_w`
-  // must first wait for that unit's wgrad.
-  auto wait_wgrad = [&]() -> int {
-    if (pending_w >= 0) {
-      TDX_HIP(hipStreamWaitEvent(st, u->ev_w[pending_w], 0));
-      pending_w = -1;
+  // Activation gradients rotate through FOUR buffers, handed out least-recently-used: the weight
+  // gradient of unit u (side stream) keeps reading dy(u) while the main stream is already two
+  // units further down, so the two streams are coupled loosely - the side stream works through
+  // its queue of wgrad GEMMs back to back and fills the gaps the main stream's HBM-bound
+  // BN / pool / resize kernels would otherwise leave on the matrix cores.  (With two ping-pong
+  // buffers every dgrad had to wait for the previous unit's wgrad: lockstep.)
+  typedef tdx_unet::GBuf GBuf;
+  GBuf* gb = u->gb;
+  int& clock = u->clock;
+  if (stage_lo == 0) {
+    float* base[4] = {ws + L.G1, ws + L.G2, ws + L.G3, ws + L.G4};
+    for (int i = 0; i < 4; ++i) gb[i] = GBuf{base[i], -1, -1, 0};
+    clock = 0;
+  } else if (gb[0].p != ws + L.G1) {
+    return TDX_E_STATE;  // another workspace than the one stage 0 ran on
+  }
+  auto find = [&](const float* p) -> GBuf* {
+    for (int i = 0; i < 4; ++i)
+      if (gb[i].p == p) return &gb[i];
+    return nullptr;
+  };
+  auto touch = [&](const float* p) { if (GBuf* b = find(p)) b->age = ++clock; };
+  // a buffer to overwrite: not `a`, not `b`; waits (on the main stream) for its last readers
+  auto acquire = [&](const float* a, const float* b, float** out) -> int {
+    GBuf* best = nullptr;
+    for (int i = 0; i < 4; ++i) {
+      GBuf& c = gb[i];
+      if (c.p != a && c.p != b && (!best || c.age < best->age)) best = &c;
     }
+    if (best->w_unit >= 0) TDX_HIP(hipStreamWaitEvent(st, u->ev_w[best->w_unit], 0));
+    if (best->s2 >= 0) TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[best->s2], 0));
+    best->w_unit = -1;
+    best->s2 = -1;
+    best->age = ++clock;
+    *out = best->p;
     return 0;
   };
-  auto unit_bwd = [&](int i, const float* in) -> int {
-    // g_of[i] holds dL/d(activation of unit i); afterwards it holds dL/d(conv output) and the
-    // input gradient is in the other ping-pong buffer
+  if (stage_lo > 0 && !find(u->g_next)) return TDX_E_STATE;  // stages must be run in order after a forward
+  float* g_next = u->g_next;
+
+  tdx_stream_t side = reinterpret_cast<tdx_stream_t>(u->side);
+  // unit_bwd: g_next holds dL/d(activation of unit i); afterwards that buffer holds
+  // dL/d(conv output) (read by the wgrad on the side stream) and *g_in_out the input gradient
+  auto unit_bwd = [&](int i, const float* in, float** g_in_out) -> int {
     const UnitDef& d = S.units[i];
-    float* g = g_of[i];
-    float* g_in = other(g);
+    float* g = g_next;
     const float* ss = ws + L.ss[i];
     const int64_t rows = (int64_t)B * d.hw * d.hw;
     RC(tdx_bn_relu_bwd(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
@@ -516,12 +575,21 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     RC(tdx_conv3x3_wgrad_reduce_pad(ws + L.slabs, G[TDX_P_UNIT0 + 4 * i],
                                     tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
                                     d.cin_real, side));
-    // main: input gradient = the forward kernel on the flipped pack, channels swapped.
-    // It writes the OTHER ping-pong buffer, whose previous dy reader must be done.
-    RC(wait_wgrad());
+    GBuf* gbuf = find(g);
+    gbuf->w_unit = i;
+    gbuf->age = ++clock;
+    // main: input gradient = the forward kernel on the flipped pack, channels swapped
+    float* g_in;
+    RC(acquire(g, nullptr, &g_in));
     RC(tdx_conv3x3_fwd(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0,
                        nullptr, nullptr, nullptr, nullptr, nullptr, stream));
-    pending_w = i;
+    *g_in_out = g_in;
+    return 0;
+  };
+  auto plain_unit_bwd = [&](int i, const float* in) -> int {
+    float* g_in;
+    RC(unit_bwd(i, in, &g_in));
+    g_next = g_in;
     return 0;
   };
   auto ssc = [&](int i) { return ws + L.ss[i]; };
@@ -535,23 +603,39 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     const UnitDef& da = S.units[ua];
     const UnitDef& dp = S.units[prev];
     const int c_up = dp.cout, c_skip = S.skip_ch[skip_k];
-    RC(unit_bwd(ua, ws + L.cat[k]));
-    float* gcat = other(g_of[ua]);
-    RC(wait_wgrad());  // the buffer holding this unit's dy is overwritten next
-    RC(tdx_bilinear_ac_bwd(gcat, g_of[prev], B, dp.hw, dp.hw, da.hw, da.hw, c_up, da.cin, 0, stream));
+    float* gcat;
+    RC(unit_bwd(ua, ws + L.cat[k], &gcat));
+    // skip branch (needed only when the encoder is reached): third stream
+    TDX_HIP(hipEventRecord(u->ev_s2_fork[k], st));
+    TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_s2_fork[k], 0));
     RC(tdx_bilinear_ac_bwd(gcat, ws + L.GS[skip_k], B, S.enc_hw[skip_k], S.enc_hw[skip_k], da.hw, da.hw,
-                           c_skip, da.cin, c_up, stream));
-    return tdx_pixel_sum(ws + L.GS[skip_k], ws + L.gtp[skip_k], B, S.enc_hw[skip_k] * S.enc_hw[skip_k], c_skip, st);
+                           c_skip, da.cin, c_up, reinterpret_cast<tdx_stream_t>(u->side2)));
+    RC(tdx_pixel_sum(ws + L.GS[skip_k], ws + L.gtp[skip_k], B, S.enc_hw[skip_k] * S.enc_hw[skip_k], c_skip,
+                     u->side2));
+    TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
+    find(gcat)->s2 = k;
+    float* gup;
+    RC(acquire(gcat, nullptr, &gup));
+    RC(tdx_bilinear_ac_bwd(gcat, gup, B, dp.hw, dp.hw, da.hw, da.hw, c_up, da.cin, 0, stream));
+    touch(gcat);
+    g_next = gup;
+    return 0;
   };
   // first unit of an encoder level below the top, or the bottleneck (units 6, 4, 2): its input is a
   // pooled tensor; route the gradient through the max-pool and add the skip-path gradient
   auto pooled_unit_bwd = [&](int ui, int k) -> int {  // k: encoder level whose output was pooled (2, 1, 0)
-    RC(unit_bwd(ui, ws + L.ep[k]));
-    float* gpool = other(g_of[ui]);
+    float* gpool;
+    RC(unit_bwd(ui, ws + L.ep[k], &gpool));
     const int ub = 2 * k + 1;  // unit producing the pooled activation (5, 3, 1)
-    RC(wait_wgrad());
-    return tdx_maxpool2_ceil_bwd(ws + L.Y[ub], ssc(ub), ssh(ub), gpool, ws + L.GS[k], g_of[ub], B,
-                                 S.enc_hw[k], S.enc_hw[k], S.skip_ch[k], stream);
+    float* gnew;
+    RC(acquire(gpool, nullptr, &gnew));
+    // GS[k] was written on the third stream during the decoder
+    TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[2 - k], 0));
+    RC(tdx_maxpool2_ceil_bwd(ws + L.Y[ub], ssc(ub), ssh(ub), gpool, ws + L.GS[k], gnew, B, S.enc_hw[k],
+                             S.enc_hw[k], S.skip_ch[k], stream));
+    touch(gpool);
+    g_next = gnew;
+    return 0;
   };
 
   for (int s = stage_lo; s < stage_hi; ++s) {
@@ -561,27 +645,33 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
         TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
         RC(tdx_final_conv_wgrad(ws + L.d1a, d_out, ws + L.smallp2, G[TDX_P_FINAL_W], G[TDX_P_FINAL_B], B,
                                 S.out_hw, S.out_hw, S.in_ch, u->side));
-        RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], G1, B, S.out_hw, S.out_hw, S.in_ch, st));
-        RC(tdx_bilinear_ac_bwd(G1, G2, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
+        {
+          float *gd1a, *g12;
+          RC(acquire(nullptr, nullptr, &gd1a));
+          RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], gd1a, B, S.out_hw, S.out_hw, S.in_ch, st));
+          RC(acquire(gd1a, nullptr, &g12));
+          RC(tdx_bilinear_ac_bwd(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
+          g_next = g12;
+        }
         break;
-      case 1: RC(unit_bwd(12, ws + L.Y[11])); break;
+      case 1: RC(plain_unit_bwd(12, ws + L.Y[11])); break;
       case 2: RC(dec_level_bwd(2)); break;
-      case 3: RC(unit_bwd(10, ws + L.Y[9])); break;
+      case 3: RC(plain_unit_bwd(10, ws + L.Y[9])); break;
       case 4: RC(dec_level_bwd(1)); break;
-      case 5: RC(unit_bwd(8, ws + L.Y[7])); break;
+      case 5: RC(plain_unit_bwd(8, ws + L.Y[7])); break;
       case 6: RC(dec_level_bwd(0)); break;
       case 7: RC(pooled_unit_bwd(6, 2)); break;
-      case 8: RC(unit_bwd(5, ws + L.Y[4])); break;
+      case 8: RC(plain_unit_bwd(5, ws + L.Y[4])); break;
       case 9: RC(pooled_unit_bwd(4, 1)); break;
-      case 10: RC(unit_bwd(3, ws + L.Y[2])); break;
+      case 10: RC(plain_unit_bwd(3, ws + L.Y[2])); break;
       case 11: RC(pooled_unit_bwd(2, 0)); break;
-      case 12: RC(unit_bwd(1, ws + L.Y[0])); break;
-      case 13: RC(unit_bwd(0, ws + L.x0)); break;  // g(x0) lands in G1
+      case 12: RC(plain_unit_bwd(1, ws + L.Y[0])); break;
+      case 13: RC(plain_unit_bwd(0, ws + L.x0)); break;  // g(x0)
       case 14:
         // the time / class path only needs the three pixel sums: side stream, beside initial_conv
         TDX_HIP(hipEventRecord(u->ev_fork, st));
         TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-        RC(tdx_initial_conv_wgrad(ws + L.x, G1, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
+        RC(tdx_initial_conv_wgrad(ws + L.x, g_next, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
                                   S.hw0, S.in_ch, S.x0_real, st));
         RC(tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
                               u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
@@ -590,8 +680,22 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
         break;
     }
   }
-  // join: everything the side stream did is ordered before whatever follows on `stream`
+  u->g_next = g_next;
+  // After the LAST stage everything the side streams did is ordered before whatever follows on
+  // `stream`.  A partial range does not join (the main stream would stall on weight-gradient
+  // GEMMs it does not depend on): tdx_unet_backward_join() orders a stream of the caller's
+  // choice - the one its gradient all-reduce runs on - after the work enqueued so far.
+  if (stage_hi == N_STAGES) return tdx_unet_backward_join(u, stream);
+  return 0;
+}
+
+extern "C" int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream) {
+  if (!u) return TDX_E_BADARG;
+  if (!u->spec) return 0;  // the latent MLP runs on one stream
+  hipStream_t st = to_stream(stream);
   TDX_HIP(hipEventRecord(u->ev_join, u->side));
   TDX_HIP(hipStreamWaitEvent(st, u->ev_join, 0));
+  TDX_HIP(hipEventRecord(u->ev_join2, u->side2));
+  TDX_HIP(hipStreamWaitEvent(st, u->ev_join2, 0));
   return 0;
 }

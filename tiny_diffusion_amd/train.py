@@ -124,6 +124,7 @@ class TrainStep:
         assert self.buckets[-1][0] == self.n_stages - 1
         self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
         self.world = self.reducer.world
+        self.comm = None  # communication stream (created on first use when there is a collective)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ setup
@@ -173,11 +174,24 @@ class TrainStep:
         d_out = torch.empty_like(eps_hat)
         check(lib.tdx_mse_loss(eps_hat.data_ptr(), noise.data_ptr(), self.loss.data_ptr(), d_out.data_ptr(),
                                1.0, eps_hat.numel(), st), "tdx_mse_loss")      # diffusion.py:231
-        lo_stage = 0
-        for bi, (last_stage, _) in enumerate(self.buckets):                    # diffusion.py:235
-            m._run_backward(plan, d_out, self.grad_views, lo_stage, last_stage + 1)
-            lo_stage = last_stage + 1
-            self.reducer.launch(bi)          # overlaps with the next stages' kernels
+        if self.world == 1 and not self.reducer.force:
+            m._run_backward(plan, d_out, self.grad_views)                      # diffusion.py:235
+        else:
+            # bucket by bucket: the collective of a finished bucket runs on the communication
+            # stream (ordered after the compute stream and the library's internal streams)
+            # while the compute stream carries on with the next stages
+            cur = torch.cuda.current_stream(dev)
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(dev)
+            lo_stage = 0
+            for bi, (last_stage, _) in enumerate(self.buckets):
+                m._run_backward(plan, d_out, self.grad_views, lo_stage, last_stage + 1)
+                lo_stage = last_stage + 1
+                self.comm.wait_stream(cur)
+                check(lib.tdx_unet_backward_join(plan.handle, self.comm.cuda_stream), "tdx_unet_backward_join")
+                with torch.cuda.stream(self.comm):
+                    self.reducer.launch(bi)
+            cur.wait_stream(self.comm)
         gscale = self.reducer.finish()
         if self.max_grad_norm is not None:
             # the flat buffer holds every gradient: one norm, one scale (stays on the device)

@@ -1,0 +1,41 @@
+"""Per training step: wall time, time covered by conv kernels, and which kernels run in the gaps
+(rocprofv3 kernel trace of `bench.py --no-extras`)."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+a, b = adam[10], adam[11]
+seg = rows[a + 1:b + 1]
+t0 = int(seg[0]["Start_Timestamp"]); t1 = int(seg[-1]["End_Timestamp"])
+print("step wall ms", (t1 - t0) / 1e6, "kernels", len(seg))
+
+
+def isconv(n):
+    return "conv3x3_igemm" in n or "conv3x3_wgrad" in n
+
+
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg if isconv(r["Kernel_Name"]))
+cov = 0; cs, ce = iv[0]; gaps = []
+for s, e in iv[1:]:
+    if s > ce:
+        cov += ce - cs; gaps.append((ce, s)); cs, ce = s, e
+    else:
+        ce = max(ce, e)
+cov += ce - cs
+print("conv-covered ms", cov / 1e6, "uncovered ms", (t1 - t0 - cov) / 1e6)
+print("sum of conv kernel durations ms", sum(e - s for s, e in iv) / 1e6)
+attr = collections.Counter()
+allgaps = [(t0, iv[0][0])] + gaps + [(ce, t1)]
+for r in seg:
+    if isconv(r["Kernel_Name"]):
+        continue
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    for gs, ge in allgaps:
+        o = min(e, ge) - max(s, gs)
+        if o > 0:
+            attr[r["Kernel_Name"][:50]] += o
+for k, v in attr.most_common(16):
+    print(f"{k:50s} {v / 1e3:8.1f} us")
