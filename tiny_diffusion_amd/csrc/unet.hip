@@ -67,7 +67,7 @@ struct Layout {
   size_t ep[3], cat[3], d1a;    // pooled encoder outputs, decoder inputs (cat[0] = level 3), resized d1
   size_t stats;                 // conv epilogue partials (largest unit)
   // backward
-  size_t G1, G2, G3, G4, GS[3], gtp[3], slabs, bnscr, smallp, smallp2, timescr;
+  size_t G1, G2, G3, G4, GS[3], gtp[3], slabs, slabs2, bnscr, smallp, smallp2, timescr;
   size_t gbuf;                  // floats in EACH of G1..G4
   size_t total;
 };
@@ -111,6 +111,7 @@ Layout make_layout(const NetSpec& S, int B) {
     L.gtp[k] = take(b * S.skip_ch[k]);
   }
   L.slabs = take(slabs);
+  L.slabs2 = take(slabs);
   L.bnscr = take(bnscr);
   L.smallp = take((size_t)tdx_small_conv_wgrad_blocks(B, S.hw0, S.hw0) * tdx_small_conv_partial_width());
   L.smallp2 = take((size_t)tdx_small_conv_wgrad_blocks(B, S.hw0, S.hw0) * tdx_small_conv_partial_width());
@@ -134,6 +135,7 @@ struct tdx_unet {
   float* g_next;                // where the gradient w.r.t. the next unit's activation lives
   struct GBuf { float* p; int w_unit; int s2; int age; } gb[4];  // rotating gradient buffers + last readers
   int clock;
+  bool red_pending[13];         // slab reduction of unit i enqueued (third stream) and not yet waited for
   // backward runs the weight-gradient GEMMs on a second (low-priority) HIP stream so that
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
@@ -142,7 +144,7 @@ struct tdx_unet {
   // third stream: the HBM-bound skip-branch resizes (forward and backward) run beside the
   // convolutions instead of between them
   hipStream_t side2;
-  hipEvent_t ev_s2_fork[3], ev_s2_done[3], ev_join2;
+  hipEvent_t ev_s2_fork[3], ev_s2_done[3], ev_join2, ev_red[13];
 };
 
 extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes) {
@@ -193,6 +195,7 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
     (void)hipEventCreateWithFlags(&u->ev_s2_done[i], hipEventDisableTiming);
   }
   (void)hipEventCreateWithFlags(&u->ev_join2, hipEventDisableTiming);
+  for (int i = 0; i < 13; ++i) (void)hipEventCreateWithFlags(&u->ev_red[i], hipEventDisableTiming);
   *out = u;
   return 0;
 }
@@ -217,6 +220,7 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
     (void)hipEventDestroy(u->ev_s2_done[i]);
   }
   (void)hipEventDestroy(u->ev_join2);
+  for (int i = 0; i < 13; ++i) (void)hipEventDestroy(u->ev_red[i]);
   (void)hipStreamDestroy(u->side2);
   (void)hipStreamDestroy(u->side);
   (void)hipFree(u->wpack);
@@ -307,20 +311,11 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     pb.cout[i] = d.cout; pb.cin[i] = d.cin; pb.cin_real[i] = d.cin_real;
   }
   if (overlap) {
-    TdxPackBatch head = pb, tail = pb;
+    // head now; the tail is launched by pack_tail() once the main stream has MFMA work in flight
+    // (beside the tiny kernels at the start of a step it only slowed them down)
+    TdxPackBatch head = pb;
     head.count = 2;
-    tail.count = 11;
-    for (int i = 0; i < 11; ++i) {
-      tail.w[i] = pb.w[i + 2]; tail.wf[i] = pb.wf[i + 2]; tail.wd[i] = pb.wd[i + 2];
-      tail.cout[i] = pb.cout[i + 2]; tail.cin[i] = pb.cin[i + 2]; tail.cin_real[i] = pb.cin_real[i + 2];
-    }
-    hipStream_t st = to_stream(stream);
-    TDX_HIP(hipEventRecord(u->ev_fork, st));            // the parameters are final on the main stream
-    TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-    int rc = tdx_pack_conv3x3_batch(&tail, reinterpret_cast<tdx_stream_t>(u->side));
-    if (rc) return rc;
-    TDX_HIP(hipEventRecord(u->ev_pack, u->side));
-    rc = tdx_pack_conv3x3_batch(&head, stream);
+    int rc = tdx_pack_conv3x3_batch(&head, stream);
     if (rc) return rc;
   } else {
     int rc = tdx_pack_conv3x3_batch(&pb, stream);
@@ -346,6 +341,26 @@ extern "C" int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const
                              tdx_stream_t stream) {
   if (!u || !params || !buffers) return TDX_E_BADARG;
   return pack_impl(u, params, buffers, stream);
+}
+
+// packs of units 2..12 on the side stream, ordered after what the main stream has enqueued so far
+static int pack_tail(tdx_unet* u, const void* const* params, tdx_stream_t stream) {
+  const float* const* P = reinterpret_cast<const float* const*>(params);
+  TdxPackBatch tail;
+  tail.count = 11;
+  for (int i = 0; i < 11; ++i) {
+    const UnitDef& d = u->spec->units[i + 2];
+    tail.w[i] = P[TDX_P_UNIT0 + 4 * (i + 2)];
+    tail.wf[i] = u->wpack + u->wf_off[i + 2];
+    tail.wd[i] = u->wpack + u->wd_off[i + 2];
+    tail.cout[i] = d.cout; tail.cin[i] = d.cin; tail.cin_real[i] = d.cin_real;
+  }
+  TDX_HIP(hipEventRecord(u->ev_fork, to_stream(stream)));
+  TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+  int rc = tdx_pack_conv3x3_batch(&tail, reinterpret_cast<tdx_stream_t>(u->side));
+  if (rc) return rc;
+  TDX_HIP(hipEventRecord(u->ev_pack, u->side));
+  return 0;
 }
 
 #define RC(call)            \
@@ -436,6 +451,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
 
   // encoder: two units per level, then 2x2 max-pool of relu(bn(.))
   RC(run_unit(0, ws + L.x0));
+  if (!infer) RC(pack_tail(u, params, stream));  // beside unit 1's convolution
   for (int k = 0; k < 3; ++k) {
     const int ua = 2 * k, ub = 2 * k + 1;
     if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
@@ -522,6 +538,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     float* base[4] = {ws + L.G1, ws + L.G2, ws + L.G3, ws + L.G4};
     for (int i = 0; i < 4; ++i) gb[i] = GBuf{base[i], -1, -1, 0};
     clock = 0;
+    for (int i = 0; i < 13; ++i) u->red_pending[i] = false;
   } else if (gb[0].p != ws + L.G1) {
     return TDX_E_STATE;  // another workspace than the one stage 0 ran on
   }
@@ -567,14 +584,24 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     TDX_HIP(hipStreamWaitEvent(u->side, u->ev_dy[i], 0));
     const float* isc = d.in_bn ? ws + L.ss[i - 1] : nullptr;
     const float* ish = d.in_bn ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
-    RC(tdx_conv3x3_wgrad(in, g, ws + L.slabs, B, d.hw, d.hw, d.cin, d.cout,
+    // The split-K slabs alternate between two buffers; the (HBM-bound) slab reduction runs on the
+    // third stream so that the side stream goes straight on to the next wgrad GEMM.  Unit i's
+    // slab buffer was last read by the reduction of unit i+2.
+    float* slab = ws + ((i & 1) ? L.slabs2 : L.slabs);
+    if (i + 2 < 13 && u->red_pending[i + 2]) {
+      TDX_HIP(hipStreamWaitEvent(u->side, u->ev_red[i + 2], 0));
+      u->red_pending[i + 2] = false;
+    }
+    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout,
                          d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish, side));
-    // dy is free again once the wgrad GEMM has read it; the slab reduction that follows only
-    // touches side-stream buffers and is covered by the join at the end of the call
+    // dy is free again once the wgrad GEMM has read it
     TDX_HIP(hipEventRecord(u->ev_w[i], u->side));
-    RC(tdx_conv3x3_wgrad_reduce_pad(ws + L.slabs, G[TDX_P_UNIT0 + 4 * i],
+    TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_w[i], 0));
+    RC(tdx_conv3x3_wgrad_reduce_pad(slab, G[TDX_P_UNIT0 + 4 * i],
                                     tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
-                                    d.cin_real, side));
+                                    d.cin_real, reinterpret_cast<tdx_stream_t>(u->side2)));
+    TDX_HIP(hipEventRecord(u->ev_red[i], u->side2));
+    u->red_pending[i] = true;
     GBuf* gbuf = find(g);
     gbuf->w_unit = i;
     gbuf->age = ++clock;
@@ -668,15 +695,16 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 12: RC(plain_unit_bwd(1, ws + L.Y[0])); break;
       case 13: RC(plain_unit_bwd(0, ws + L.x0)); break;  // g(x0)
       case 14:
-        // the time / class path only needs the three pixel sums: side stream, beside initial_conv
+        // the time / class path only needs the three pixel sums (third stream, in order there):
+        // beside initial_conv's weight gradient and the last wgrad GEMMs
         TDX_HIP(hipEventRecord(u->ev_fork, st));
-        TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
+        TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
         RC(tdx_initial_conv_wgrad(ws + L.x, g_next, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
                                   S.hw0, S.in_ch, S.x0_real, st));
         RC(tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
                               u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
                               P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side));
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2));
         break;
     }
   }
