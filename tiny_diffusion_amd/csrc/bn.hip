@@ -14,40 +14,57 @@
 //     M2 = sum_t M2_t + sum_t S_t^2 / n_t - S^2 / N ,   S = sum_t S_t
 // The last two terms cancel, but they are accumulated in double: with |mean|/std up to 1e4 that
 // still leaves 8 significant digits, while the fp32-sensitive part (deviations inside a tile)
-// was centred before it was ever summed.  block = 4 channels x 64 interleaved tile slices
-// (many small blocks: the kernel sits on the critical path between two convolutions).
+// was centred before it was ever summed.  block = 4 channels (one float4 per tile) x 256
+// interleaved tile slices, then a fixed-order tree (the kernel sits on the critical path between two
+// convolutions: all loads of a thread are in flight together).
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t count, int C,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    float* __restrict__ rmean, float* __restrict__ rvar,
                    int64_t* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ save_mean, float* __restrict__ save_rstd, int training) {
-  __shared__ double red[3][64][4];
-  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
+  __shared__ double red[3][4][256];
+  const int c0 = blockIdx.x * 4;      // this block's 4 channels (C % 4 == 0)
+  const int sl = threadIdx.x;         // tile slice: every thread reads float4 = 4 channels of one tile
+  const int cl = threadIdx.x & 3;
+  const int c = c0 + cl;
   if (training) {
-    double S = 0.0, Q = 0.0, R = 0.0;
-    if (c < C) {
+    double S[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+    {
       const double inv_full = 1.0 / (double)tile_rows;
       const int64_t last_rows = count - (int64_t)(tiles - 1) * tile_rows;
       const double inv_last = 1.0 / (double)last_rows;
 #pragma unroll 4
-      for (int t = sl; t < tiles; t += 64) {
-        const double st = (double)stats[((size_t)t * 2 + 0) * C + c];
-        const double qt = (double)stats[((size_t)t * 2 + 1) * C + c];
-        S += st;
-        Q += qt;
-        R += st * st * (t == tiles - 1 ? inv_last : inv_full);
+      for (int t = sl; t < tiles; t += 256) {
+        const float4 st = *reinterpret_cast<const float4*>(stats + ((size_t)t * 2 + 0) * C + c0);
+        const float4 qt = *reinterpret_cast<const float4*>(stats + ((size_t)t * 2 + 1) * C + c0);
+        const double inv = t == tiles - 1 ? inv_last : inv_full;
+        const float sv[4] = {st.x, st.y, st.z, st.w}, qv[4] = {qt.x, qt.y, qt.z, qt.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          S[k] += (double)sv[k];
+          Q[k] += (double)qv[k];
+          R[k] += (double)sv[k] * (double)sv[k] * inv;
+        }
       }
     }
-    red[0][sl][cl] = S;
-    red[1][sl][cl] = Q;
-    red[2][sl][cl] = R;
-    __syncthreads();
-    if (sl == 0 && c < C) {
-      S = 0.0; Q = 0.0; R = 0.0;
 #pragma unroll
-      for (int k = 0; k < 64; ++k) { S += red[0][k][cl]; Q += red[1][k][cl]; R += red[2][k][cl]; }
+    for (int k = 0; k < 4; ++k) { red[0][k][sl] = S[k]; red[1][k][sl] = Q[k]; red[2][k][sl] = R[k]; }
+    __syncthreads();
+    // fixed-order tree over the 256 slices (deterministic)
+    for (int half = 128; half > 0; half >>= 1) {
+      if (sl < half) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          red[0][k][sl] += red[0][k][sl + half];
+          red[1][k][sl] += red[1][k][sl + half];
+          red[2][k][sl] += red[2][k][sl + half];
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 4 && c < C) {
+      const double S = red[0][cl][0], Q = red[1][cl][0], R = red[2][cl][0];
       const double n = (double)count;
       const double mean = S / n;
       double m2 = Q + (R - S * S / n);
@@ -66,7 +83,7 @@ bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, in
       }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
-  } else if (sl == 0 && c < C) {
+  } else if (threadIdx.x < 4 && c < C) {
     const float mean = rmean[c];
     const float rstd = 1.0f / sqrtf(rvar[c] + BN_EPS);
     const float sc = gamma[c] * rstd;
@@ -153,23 +170,32 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count
                        const float* __restrict__ scale, float* __restrict__ dgamma,
                        float* __restrict__ dbeta, float* __restrict__ dbias,
                        float* __restrict__ coef, int training) {
-  __shared__ double red[2][64][4];
-  const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
-  const int c = blockIdx.x * 4 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-#pragma unroll 8
-    for (int t = sl; t < nblk; t += 64) {
-      s1 += (double)partial[((size_t)t * 2 + 0) * C + c];
-      s2 += (double)partial[((size_t)t * 2 + 1) * C + c];
-    }
+  __shared__ double red[2][4][256];
+  const int c0 = blockIdx.x * 4, sl = threadIdx.x, cl = threadIdx.x & 3;
+  const int c = c0 + cl;
+  double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+#pragma unroll 4
+  for (int t = sl; t < nblk; t += 256) {
+    const float4 p1 = *reinterpret_cast<const float4*>(partial + ((size_t)t * 2 + 0) * C + c0);
+    const float4 p2 = *reinterpret_cast<const float4*>(partial + ((size_t)t * 2 + 1) * C + c0);
+    a1[0] += (double)p1.x; a1[1] += (double)p1.y; a1[2] += (double)p1.z; a1[3] += (double)p1.w;
+    a2[0] += (double)p2.x; a2[1] += (double)p2.y; a2[2] += (double)p2.z; a2[3] += (double)p2.w;
   }
-  red[0][sl][cl] = s1;
-  red[1][sl][cl] = s2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][k][sl] = a1[k]; red[1][k][sl] = a2[k]; }
   __syncthreads();
-  if (sl == 0 && c < C) {
-    s1 = 0.0; s2 = 0.0;
-    for (int k = 0; k < 64; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+  for (int half = 128; half > 0; half >>= 1) {
+    if (sl < half) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[0][k][sl] += red[0][k][sl + half];
+        red[1][k][sl] += red[1][k][sl + half];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && c < C) {
+    const double s1 = red[0][cl][0], s2 = red[1][cl][0];
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     if (training) {

@@ -685,6 +685,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }
   if (!strcmp(key, "conv_impl")) { g_conv_impl = value < 0 || value > 2 ? 0 : value; return 0; }
   if (!strcmp(key, "splitk")) { g_splitk = value; return 0; }
+  if (!strcmp(key, "streams")) { g_tdx_streams = value; return 0; }
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }

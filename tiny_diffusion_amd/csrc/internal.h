@@ -56,3 +56,6 @@ int tdx_latent_forward(const float* const* P, void* const* buffers, const float*
 int tdx_latent_backward(const float* const* P, float* const* G, const float* d_out, float* ws, int B,
                         int training, int stage_lo, int stage_hi, int ncls, hipStream_t st);
 int tdx_latent_tensor(int B, const char* name, size_t* off, size_t* numel);
+// tuning knob "streams" (A/B experiments): -1 per-network default, 0 / 1 = plans created afterwards
+// run training on one stream / on the three-stream schedule
+extern int g_tdx_streams;

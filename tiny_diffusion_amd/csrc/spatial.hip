@@ -424,7 +424,7 @@ int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, floa
 
 // dW[co][ci][tap] = sum_p g[p][co] * x[n][ci][p+tap];  db[co] = sum_p g[p][co]
 // partial[blk][SMALLP_W]: [(co*CIN+ci)*9+tap] then [COR*CIN*9 + co]
-#define ICW_PIX 256
+#define ICW_PIX 64   // pixels per block: small, so that the grid has thousands of blocks (the kernels are latency-bound)
 template <int CIN, int COR>
 __global__ void __launch_bounds__(256)
 initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,

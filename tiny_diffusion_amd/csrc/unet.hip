@@ -36,6 +36,7 @@ struct UnitDef {
 struct NetSpec {
   int in_ch, hw0, out_hw;  // model input channels / resolution, output resolution
   int x0_ch, x0_real;      // initial_conv output channels as stored / in the reference
+  int overlap;             // 1: training runs on three streams (see tdx_unet_backward); 0: one stream
   int time_dim;
   int enc_hw[4];           // resolutions of enc1, enc2, enc3, bottleneck
   int dec_hw[3];           // resolutions of dec3, dec2, dec1
@@ -44,18 +45,21 @@ struct NetSpec {
 };
 
 const NetSpec SPECS[2] = {
-    {1, 28, 28, 64, 64, 256, {28, 14, 7, 4}, {8, 16, 32}, {128, 256, 512},
+    {1, 28, 28, 64, 64, 1, 256, {28, 14, 7, 4}, {8, 16, 32}, {128, 256, 512},
      {{64, 128, 28, 0, 64},  {128, 128, 28, 1, 128}, {128, 256, 14, 0, 128}, {256, 256, 14, 1, 256},
       {256, 512, 7, 0, 256}, {512, 512, 7, 1, 512},  {512, 512, 4, 0, 512},  {1024, 256, 8, 0, 1024},
       {256, 256, 8, 1, 256}, {512, 128, 16, 0, 512}, {128, 128, 16, 1, 128}, {256, 64, 32, 0, 256},
       {64, 64, 32, 1, 64}}},
-    {4, 32, 32, 64, 32, 768, {32, 16, 8, 4}, {8, 16, 32}, {64, 128, 256},
+    // overlap = 0: this network's thin 64-channel layers at 32x32 are close to the HBM roofline and
+    // need the L2s to themselves (measured at B=256: 11.7 ms/step on one stream, 14.4 on three)
+    {4, 32, 32, 64, 32, 0, 768, {32, 16, 8, 4}, {8, 16, 32}, {64, 128, 256},
      {{64, 64, 32, 0, 32},   {64, 64, 32, 1, 64},    {64, 128, 16, 0, 64},   {128, 128, 16, 1, 128},
       {128, 256, 8, 0, 128}, {256, 256, 8, 1, 256},  {256, 256, 4, 0, 256},  {512, 256, 8, 0, 512},
       {256, 256, 8, 1, 256}, {384, 128, 16, 0, 384}, {128, 128, 16, 1, 128}, {192, 64, 32, 0, 192},
       {64, 64, 32, 1, 64}}}};
 
 constexpr int N_STAGES = 15;
+
 
 inline size_t align64(size_t n) { return (n + 63) / 64 * 64; }
 
@@ -122,6 +126,8 @@ Layout make_layout(const NetSpec& S, int B) {
 
 }  // namespace
 
+int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
+
 struct tdx_unet {
   int max_batch, num_classes, kind;
   const NetSpec* spec;
@@ -139,6 +145,8 @@ struct tdx_unet {
   // backward runs the weight-gradient GEMMs on a second (low-priority) HIP stream so that
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
+  bool use_streams;             // false: `side` / `side2` alias the caller's stream for the current call
+  hipStream_t side_own, side2_own;
   hipStream_t side;
   hipEvent_t ev_dy[13], ev_w[13], ev_join, ev_fork, ev_pack;
   // third stream: the HBM-bound skip-branch resizes (forward and backward) run beside the
@@ -179,7 +187,8 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   u->g_next = nullptr;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
-  e = hipStreamCreateWithPriority(&u->side, hipStreamNonBlocking, lo);
+  u->use_streams = g_tdx_streams < 0 ? (u->spec && u->spec->overlap) : g_tdx_streams != 0;
+  e = hipStreamCreateWithPriority(&u->side_own, hipStreamNonBlocking, lo);
   if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); delete u; return (int)e; }
   for (int i = 0; i < 13; ++i) {
     (void)hipEventCreateWithFlags(&u->ev_dy[i], hipEventDisableTiming);
@@ -188,8 +197,10 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   (void)hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_pack, hipEventDisableTiming);
-  e = hipStreamCreateWithFlags(&u->side2, hipStreamNonBlocking);
+  e = hipStreamCreateWithFlags(&u->side2_own, hipStreamNonBlocking);
   if (e != hipSuccess) return (int)e;
+  u->side = u->side_own;
+  u->side2 = u->side2_own;
   for (int i = 0; i < 3; ++i) {
     (void)hipEventCreateWithFlags(&u->ev_s2_fork[i], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&u->ev_s2_done[i], hipEventDisableTiming);
@@ -206,7 +217,7 @@ extern "C" int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes) {
 
 extern "C" int tdx_unet_destroy(tdx_unet* u) {
   if (!u) return TDX_E_BADARG;
-  (void)hipStreamSynchronize(u->side);
+  (void)hipStreamSynchronize(u->side_own);
   for (int i = 0; i < 13; ++i) {
     (void)hipEventDestroy(u->ev_dy[i]);
     (void)hipEventDestroy(u->ev_w[i]);
@@ -214,15 +225,15 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
   (void)hipEventDestroy(u->ev_join);
   (void)hipEventDestroy(u->ev_fork);
   (void)hipEventDestroy(u->ev_pack);
-  (void)hipStreamSynchronize(u->side2);
+  (void)hipStreamSynchronize(u->side2_own);
   for (int i = 0; i < 3; ++i) {
     (void)hipEventDestroy(u->ev_s2_fork[i]);
     (void)hipEventDestroy(u->ev_s2_done[i]);
   }
   (void)hipEventDestroy(u->ev_join2);
   for (int i = 0; i < 13; ++i) (void)hipEventDestroy(u->ev_red[i]);
-  (void)hipStreamDestroy(u->side2);
-  (void)hipStreamDestroy(u->side);
+  (void)hipStreamDestroy(u->side2_own);
+  (void)hipStreamDestroy(u->side_own);
   (void)hipFree(u->wpack);
   (void)hipFree(u->infer_ss);
   delete u;
@@ -398,6 +409,8 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const float* const* P = reinterpret_cast<const float* const*>(params);
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t st = to_stream(stream);
+  u->side = u->use_streams ? u->side_own : st;
+  u->side2 = u->use_streams ? u->side2_own : st;
   const int B = batch;
   const bool infer = mode == TDX_MODE_INFER;
   const bool training = mode == TDX_MODE_TRAIN;
@@ -523,6 +536,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   float* const* G = reinterpret_cast<float* const*>(grads);
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t st = to_stream(stream);
+  u->side = u->use_streams ? u->side_own : st;
+  u->side2 = u->use_streams ? u->side2_own : st;
   const int B = batch;
   const int training = u->saved_mode == TDX_MODE_TRAIN ? 1 : 0;
   // Activation gradients rotate through FOUR buffers, handed out least-recently-used: the weight
@@ -578,24 +593,27 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                        ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
                        G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
                        stream));
-    // fork: weight gradient on the side stream (input is the previous unit's pre-BN tensor
-    // when in_bn).  The slab buffer is only ever touched by the side stream, in order.
-    TDX_HIP(hipEventRecord(u->ev_dy[i], st));
-    TDX_HIP(hipStreamWaitEvent(u->side, u->ev_dy[i], 0));
+    // Weight gradient: forked to the side stream (which IS the main stream for networks whose
+    // NetSpec says overlap = 0).
     const float* isc = d.in_bn ? ws + L.ss[i - 1] : nullptr;
     const float* ish = d.in_bn ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
-    // The split-K slabs alternate between two buffers; the (HBM-bound) slab reduction runs on the
-    // third stream so that the side stream goes straight on to the next wgrad GEMM.  Unit i's
-    // slab buffer was last read by the reduction of unit i+2.
+    const bool fork = true;
     float* slab = ws + ((i & 1) ? L.slabs2 : L.slabs);
+    // The split-K slabs alternate between two buffers; the (HBM-bound) slab reduction runs on the
+    // third stream.  Unit i's slab buffer was last read by the reduction of unit i+2.
+    hipStream_t wst = fork ? u->side : st;
+    if (fork) {
+      TDX_HIP(hipEventRecord(u->ev_dy[i], st));
+      TDX_HIP(hipStreamWaitEvent(u->side, u->ev_dy[i], 0));
+    }
     if (i + 2 < 13 && u->red_pending[i + 2]) {
-      TDX_HIP(hipStreamWaitEvent(u->side, u->ev_red[i + 2], 0));
+      TDX_HIP(hipStreamWaitEvent(wst, u->ev_red[i + 2], 0));
       u->red_pending[i + 2] = false;
     }
-    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout,
-                         d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish, side));
+    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish,
+                         reinterpret_cast<tdx_stream_t>(wst)));
     // dy is free again once the wgrad GEMM has read it
-    TDX_HIP(hipEventRecord(u->ev_w[i], u->side));
+    TDX_HIP(hipEventRecord(u->ev_w[i], wst));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_w[i], 0));
     RC(tdx_conv3x3_wgrad_reduce_pad(slab, G[TDX_P_UNIT0 + 4 * i],
                                     tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
@@ -719,8 +737,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
 
 extern "C" int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream) {
   if (!u) return TDX_E_BADARG;
-  if (!u->spec) return 0;  // the latent MLP runs on one stream
+  if (!u->spec || !u->use_streams) return 0;  // everything already ran on the caller's stream
   hipStream_t st = to_stream(stream);
+  u->side = u->side_own;
+  u->side2 = u->side2_own;
   TDX_HIP(hipEventRecord(u->ev_join, u->side));
   TDX_HIP(hipStreamWaitEvent(st, u->ev_join, 0));
   TDX_HIP(hipEventRecord(u->ev_join2, u->side2));
