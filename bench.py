@@ -33,14 +33,18 @@ TRAIN_FLOP_PER_IMAGE = 3 * FWD_FLOP_PER_IMAGE
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md (dense fp32 matrix)
 
 # (cin, cout, H) of the 13 conv/BN units, diffusion.py:32-95
-UNITS = [(64, 128, 28), (128, 128, 28), (128, 256, 14), (256, 256, 14), (256, 512, 7), (512, 512, 7),
-         (512, 512, 4), (1024, 256, 8), (256, 256, 8), (512, 128, 16), (128, 128, 16), (256, 64, 32),
-         (64, 64, 32)]
+# (cin, cout, hw, in_bn): in_bn = the unit reads the previous unit's pre-BN tensor and applies
+# relu(y*scale+shift) on load (the second conv of every stage) - same flags as tdx_unet_forward
+UNITS = [(64, 128, 28, 0), (128, 128, 28, 1), (128, 256, 14, 0), (256, 256, 14, 1), (256, 512, 7, 0),
+         (512, 512, 7, 1), (512, 512, 4, 0), (1024, 256, 8, 0), (256, 256, 8, 1), (512, 128, 16, 0),
+         (128, 128, 16, 1), (256, 64, 32, 0), (64, 64, 32, 1)]
 
 
 def conv_roofline(B: int, reps: int = 5):
     """Time every MFMA conv launch of one training step (13 x {fwd, dgrad, wgrad}) in
-    isolation with HIP events on the launch stream; FLOPs are algorithmic (2*M*9*cin*cout)."""
+    isolation with HIP events on the launch stream, with the flags the training step uses
+    (train-mode statistics epilogue; BN+ReLU-on-load for the six units fed by a pre-BN tensor);
+    FLOPs are algorithmic (2*M*9*cin*cout)."""
     from tiny_diffusion_amd._lib import lib, check
 
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -48,7 +52,7 @@ def conv_roofline(B: int, reps: int = 5):
     rows = []
     tot_flop = tot_ms = 0.0
     n_launch = 0
-    for cin, cout, H in UNITS:
+    for cin, cout, H, in_bn in UNITS:
         M = B * H * H
         flop = 2.0 * M * 9 * cin * cout
         x = torch.randn(M * cin, device=dev)
@@ -61,18 +65,21 @@ def conv_roofline(B: int, reps: int = 5):
         splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
         slabs = torch.empty(splits * cout * 9 * cin, device=dev)
         bias = torch.zeros(cout, device=dev)
+        isc = torch.rand(cin, device=dev) + 0.5
+        ish = torch.randn(cin, device=dev) * 0.1
+        sc_p, sh_p = (isc.data_ptr(), ish.data_ptr()) if in_bn else (None, None)
 
         def fwd():
             check(lib.tdx_conv3x3_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, cin,
-                                      cout, 4, None, None, None, None, stats.data_ptr(), st))
+                                      cout, 4 | in_bn, sc_p, sh_p, None, None, stats.data_ptr(), st))
 
         def dgrad():
             check(lib.tdx_conv3x3_fwd(dy.data_ptr(), wf.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
                                       None, None, None, None, None, st))
 
         def wgrad():
-            check(lib.tdx_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 0,
-                                        None, None, st))
+            check(lib.tdx_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, in_bn,
+                                        sc_p, sh_p, st))
 
         for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
             fn(); fn()
@@ -83,7 +90,7 @@ def conv_roofline(B: int, reps: int = 5):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            rows.append({"cin": cin, "cout": cout, "hw": H, "role": name, "ms": round(ms, 4),
+            rows.append({"cin": cin, "cout": cout, "hw": H, "in_bn": in_bn, "role": name, "ms": round(ms, 4),
                          "tflops": round(flop / ms / 1e9, 1)})
             tot_flop += flop
             tot_ms += ms
