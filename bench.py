@@ -43,7 +43,8 @@ UNITS = [(64, 128, 28, 0), (128, 128, 28, 1), (128, 256, 14, 0), (256, 256, 14, 
 def conv_roofline(B: int, reps: int = 5):
     """Time every MFMA conv launch of one training step (13 x {fwd, dgrad, wgrad}) in
     isolation with HIP events on the launch stream, with the flags the training step uses
-    (train-mode statistics epilogue; BN+ReLU-on-load for the six units fed by a pre-BN tensor);
+    (train-mode statistics epilogue; the six units fed by another unit read its materialised
+    relu(bn(.)) tensor, or - with TDX_TUNE=materialize=0 - apply BN+ReLU on load);
     FLOPs are algorithmic (2*M*9*cin*cout)."""
     from tiny_diffusion_amd._lib import lib, check
 
@@ -52,7 +53,9 @@ def conv_roofline(B: int, reps: int = 5):
     rows = []
     tot_flop = tot_ms = 0.0
     n_launch = 0
+    bn_on_load = "materialize=0" in os.environ.get("TDX_TUNE", "")
     for cin, cout, H, in_bn in UNITS:
+        in_bn = in_bn if bn_on_load else 0
         M = B * H * H
         flop = 2.0 * M * 9 * cin * cout
         x = torch.randn(M * cin, device=dev)

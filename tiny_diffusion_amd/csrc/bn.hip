@@ -111,6 +111,39 @@ extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_r
   return 0;
 }
 
+// out = relu(y*scale + shift): the post-activation tensor, materialised only for the six units
+// that feed another 3x3 convolution directly, so that convolution can fetch its tiles by LDS-DMA
+// (no BN-on-load register path); everything else keeps applying scale/shift on load.
+__global__ void __launch_bounds__(256)
+bn_relu_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int64_t n4, int C,
+                     const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int c4n = C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+    o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+    o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+
+int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const float* scale, const float* shift,
+                      hipStream_t st) {
+  if (!y || !out || !scale || !shift || rows <= 0 || C <= 0 || C % 4) return TDX_E_BADARG;
+  const int64_t n4 = rows * C / 4;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  bn_relu_apply_kernel<<<grid, 256, 0, st>>>(y, out, n4, C, scale, shift);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------ backward
 // Rows per block of the reduction pass: sized so that the grid has ~2048 workgroups whatever the
 // layer (the deep layers have few rows but many channels; a fixed 512 rows per block left

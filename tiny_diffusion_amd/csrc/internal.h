@@ -59,3 +59,8 @@ int tdx_latent_tensor(int B, const char* name, size_t* off, size_t* numel);
 // tuning knob "streams" (A/B experiments): -1 per-network default, 0 / 1 = plans created afterwards
 // run training on one stream / on the three-stream schedule
 extern int g_tdx_streams;
+int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const float* scale, const float* shift,
+                      hipStream_t st);
+// tuning knob "materialize": 1 = the activation feeding the second convolution of a stage is
+// written out (post BN+ReLU) so that convolution and its wgrad run on the LDS-DMA kernels
+extern int g_tdx_materialize;

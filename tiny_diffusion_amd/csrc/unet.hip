@@ -68,6 +68,7 @@ struct Layout {
   size_t x, t, y;               // copies of the inputs (t is int64 -> 2 floats each; y: labels or embeddings)
   size_t sin, pre, emb, tp[3];  // time path: sinusoid (kind 1), first-layer pre-activation, embedding, projections
   size_t x0, Y[13], ss[13];     // ss: scale | shift | mean | rstd (4*cout)
+  size_t A[13];                 // relu(bn(Y[u])) for the units whose successor is a 3x3 conv on it (else unused)
   size_t ep[3], cat[3], d1a;    // pooled encoder outputs, decoder inputs (cat[0] = level 3), resized d1
   size_t stats;                 // conv epilogue partials (largest unit)
   // backward
@@ -91,6 +92,7 @@ Layout make_layout(const NetSpec& S, int B) {
     const UnitDef& d = S.units[u];
     L.Y[u] = take(b * d.hw * d.hw * d.cout);
     L.ss[u] = take(4 * (size_t)d.cout);
+    L.A[u] = (u + 1 < 13 && S.units[u + 1].in_bn) ? take(b * d.hw * d.hw * d.cout) : 0;
     stats = std::max(stats, (size_t)tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout) * 2 * d.cout);
     slabs = std::max(slabs, (size_t)tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout) * 9 *
                                 (size_t)d.cin * d.cout);
@@ -126,6 +128,7 @@ Layout make_layout(const NetSpec& S, int B) {
 
 }  // namespace
 
+int g_tdx_materialize = 1;
 int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
 
 struct tdx_unet {
@@ -145,6 +148,7 @@ struct tdx_unet {
   // backward runs the weight-gradient GEMMs on a second (low-priority) HIP stream so that
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
+  bool materialize;             // train: write relu(bn(Y)) of the first conv of every stage (see Layout::A)
   bool use_streams;             // false: `side` / `side2` alias the caller's stream for the current call
   hipStream_t side_own, side2_own;
   hipStream_t side;
@@ -187,6 +191,7 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   u->g_next = nullptr;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
+  u->materialize = g_tdx_materialize != 0;
   u->use_streams = g_tdx_streams < 0 ? (u->spec && u->spec->overlap) : g_tdx_streams != 0;
   e = hipStreamCreateWithPriority(&u->side_own, hipStreamNonBlocking, lo);
   if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); delete u; return (int)e; }
@@ -448,18 +453,23 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       return tdx_conv3x3_fwd_splitk(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU,
                                     nullptr, nullptr, iss, iss + d.cout, ws + L.G1, 2 * L.gbuf, stream);
     }
-    int flags = (d.in_bn ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
+    const bool bn_on_load = d.in_bn && !u->materialize;
+    if (d.in_bn && u->materialize) in = ws + L.A[i - 1];
+    int flags = (bn_on_load ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
     RC(tdx_conv3x3_fwd(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, flags,
-                       d.in_bn ? sc(i - 1) : nullptr, d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr,
+                       bn_on_load ? sc(i - 1) : nullptr, bn_on_load ? sh(i - 1) : nullptr, nullptr, nullptr,
                        ws + L.stats, stream));
     const int tiles = tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout);
-    return tdx_bn_finalize(ws + L.stats, tiles,
-                           tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout),
-                           (int64_t)B * d.hw * d.hw, d.cout,
-                           P[TDX_P_UNIT0 + 4 * i + 2], P[TDX_P_UNIT0 + 4 * i + 3],
-                           (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
-                           (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout,
-                           ss + 3 * d.cout, training ? 1 : 0, stream);
+    RC(tdx_bn_finalize(ws + L.stats, tiles,
+                       tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout),
+                       (int64_t)B * d.hw * d.hw, d.cout,
+                       P[TDX_P_UNIT0 + 4 * i + 2], P[TDX_P_UNIT0 + 4 * i + 3],
+                       (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
+                       (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout,
+                       ss + 3 * d.cout, training ? 1 : 0, stream));
+    if (u->materialize && i + 1 < 13 && S.units[i + 1].in_bn)
+      RC(tdx_bn_relu_apply(Y, ws + L.A[i], (int64_t)B * d.hw * d.hw, d.cout, ss, ss + d.cout, st));
+    return 0;
   };
 
   // encoder: two units per level, then 2x2 max-pool of relu(bn(.))
@@ -595,8 +605,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                        stream));
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
     // NetSpec says overlap = 0).
-    const float* isc = d.in_bn ? ws + L.ss[i - 1] : nullptr;
-    const float* ish = d.in_bn ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
+    const bool bn_on_load = d.in_bn && !u->materialize;
+    if (d.in_bn && u->materialize) in = ws + L.A[i - 1];  // materialised relu(bn(Y[i-1]))
+    const float* isc = bn_on_load ? ws + L.ss[i - 1] : nullptr;
+    const float* ish = bn_on_load ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
     const bool fork = true;
     float* slab = ws + ((i & 1) ? L.slabs2 : L.slabs);
     // The split-K slabs alternate between two buffers; the (HBM-bound) slab reduction runs on the
@@ -610,7 +622,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       TDX_HIP(hipStreamWaitEvent(wst, u->ev_red[i + 2], 0));
       u->red_pending[i + 2] = false;
     }
-    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, d.in_bn ? TDX_CONV_IN_BNRELU : 0, isc, ish,
+    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc, ish,
                          reinterpret_cast<tdx_stream_t>(wst)));
     // dy is free again once the wgrad GEMM has read it
     TDX_HIP(hipEventRecord(u->ev_w[i], wst));
