@@ -101,12 +101,33 @@ def conv_roofline(B: int, reps: int = 5):
     return rows, tot_flop, tot_ms, n_launch
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed PMC passes over this same leg (bench.py cannot
+    collect counters itself): tools/pmc_traffic.py -> profiles/r01_end_pmc_hbm_traffic.json."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_end_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_block(B: int):
     rows, flop, ms, nl = conv_roofline(B)
     ach = flop / ms / 1e9
+    pmc = pmc_traffic()
+    # algorithmic minimum HBM bytes of the 39 launches: read both operands once, write the result once
+    alg = 0.0
+    for cin, cout, H, _ in UNITS:
+        M = B * H * H
+        alg += 3 * 4.0 * (M * cin + M * cout + 9 * cin * cout)
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": None if pmc is None else round(pmc["traffic_mb_per_launch"] * 1e6),
+        "traffic_note": "HBM bytes per launch, rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, separate passes over this leg "
+                        "(profiles/r01_end_pmc_hbm_traffic.*); algorithmic minimum in algorithmic_bytes_per_launch",
+        "algorithmic_bytes_per_launch": round(alg / nl),
         "kernel": "conv3x3_igemm_dma_kernel / conv3x3_igemm_kernel (fwd, dgrad) + "
                   "conv3x3_wgrad_dma_kernel / conv3x3_wgrad_kernel + wgrad split reduce excluded",
         "launches_per_step": nl, "conv_ms_per_step": round(ms, 3), "avg_launch_us": round(ms / nl * 1e3, 1),

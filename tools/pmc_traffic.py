@@ -1,0 +1,47 @@
+"""HBM traffic of the convolution launches of `bench.py --roofline-only` from two rocprofv3 PMC passes
+(FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, "rocprofv3 PMC slots").
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --roofline-only
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 bench.py --roofline-only
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_end_pmc_hbm_traffic
+
+Units: rocprofv3 reports KB.  gfx950 correction (same guide, section HBM): FETCH_SIZE tallies the
+128-B requests of wide (16 B/lane) streaming reads - global_load and buffer_load...lds alike - as
+64 B, so fetched bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for 16-B-per-lane stores.
+Writes <out>.txt (per kernel) and <out>.json (per-launch average, read by bench.py)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and "conv3x3" in r["Kernel_Name"]:
+            a = agg[r["Kernel_Name"].split("(")[0]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return agg
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+nf, nw = sum(v[1] for v in fetch.values()), sum(v[1] for v in write.values())
+f_kb = sum(v[0] for v in fetch.values()) / nf
+w_kb = sum(v[0] for v in write.values()) / nw
+lines = [__doc__.split("Units:")[0].strip().splitlines()[0],
+         "KB as reported by rocprofv3; gfx950: fetched bytes = 2 x FETCH_SIZE (wide streaming reads), WRITE_SIZE exact", ""]
+for name, agg, n, avg in (("FETCH_SIZE", fetch, nf, f_kb), ("WRITE_SIZE", write, nw, w_kb)):
+    lines.append(f"{name}, conv kernels of the roofline leg: {n} launches, {avg:.0f} KB per launch on average")
+    for k, (tot, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        lines.append(f"   {k:70s} n={c:4d} per_launch_KB={tot / c:10.0f}")
+    lines.append("")
+traffic_mb = (2 * f_kb + w_kb) * 1024 / 1e6
+lines.append(f"HBM traffic per conv launch (2*FETCH+WRITE): {traffic_mb:.1f} MB")
+open(sys.argv[3] + ".txt", "w").write("\n".join(lines) + "\n")
+json.dump({"traffic_mb_per_launch": round(traffic_mb, 1), "fetch_kb_reported": round(f_kb), "write_kb_reported": round(w_kb),
+           "launches": nf, "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950, MI355X_MICROARCH.md HBM section)",
+           "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --roofline-only (two passes)"},
+          open(sys.argv[3] + ".json", "w"), indent=1)
+print("\n".join(lines[-8:]))
