@@ -186,7 +186,7 @@ _LAION_CONVS = [(4, 32, 32), (32, 64, 32), (64, 64, 32), (64, 128, 16), (128, 12
 LAION_FWD_FLOP = sum(2 * 9 * ci * co * hw * hw for ci, co, hw in _LAION_CONVS)
 
 
-def laion_extras(steps: int = 20, warmup: int = 5):
+def laion_extras(steps: int = 40, warmup: int = 8):
     """SURVEY.md 8(f) f3 (BASELINE.json configs[4] shape): training step of the LAION-shaped
     latent UNet (q_sample + fwd + MSE + bwd + clip_grad_norm(10) + Adam, cosine LR) at the
     reference's batch 8 and at 256, and the 1000-step reverse chain for its 4 prompts."""
@@ -195,11 +195,12 @@ def laion_extras(steps: int = 20, warmup: int = 5):
 
     out = {"fwd_gflop_per_sample": round(LAION_FWD_FLOP / 1e9, 3)}
     fp = ForwardProcess()
-    for B in (8, 256):
+    for B, graph in ((8, False), (256, False)):
         torch.manual_seed(0)
         model = NoiseModel(time_dim=768).cuda().train()
-        ts = TrainStep(model, fp, lr=1e-4, philox_seed=99, max_grad_norm=10.0, cosine_T_max=1000,
-                       cosine_eta_min=1e-6)
+        # graph: the whole step replayed as one HIP graph (the reference's batch size is launch-bound)
+        ts = TrainStep(model, fp, lr=1e-4, philox_seed=None if graph else 99, max_grad_norm=10.0,
+                       cosine_T_max=1000, cosine_eta_min=1e-6, use_graph=graph)
         x0 = torch.randn(B, 4, 32, 32, device="cuda") * 0.8
         cond = torch.randn(B, 768, device="cuda")
         for _ in range(warmup):
@@ -213,9 +214,10 @@ def laion_extras(steps: int = 20, warmup: int = 5):
         lv = loss.item()
         if not (lv == lv) or lv > 1e3:
             raise SystemExit(f"LAION training diverged in the benchmark: loss {lv}")
-        out[f"train_B{B}"] = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-                              "tflops": round(B * steps / dt * 3 * LAION_FWD_FLOP / 1e12, 2)}
-        if B == 8:
+        out[f"train_B{B}" + ("_graph" if graph else "")] = {
+            "samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "tflops": round(B * steps / dt * 3 * LAION_FWD_FLOP / 1e12, 2)}
+        if B == 8 and not graph:
             model.eval()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -238,10 +240,10 @@ def latent_extras(steps: int = 200, warmup: int = 20):
     torch.manual_seed(0)
     fp = ForwardProcess()
     vae = VAE(VAEConfig()).cuda().eval()
-    model = NoiseModel().cuda().train()
-    ts = TrainStep(model, fp, lr=1e-3)
     out = {}
-    for B in (128, 1024):
+    for B, graph in ((128, False), (1024, False)):
+        model = NoiseModel().cuda().train()
+        ts = TrainStep(model, fp, lr=1e-3, use_graph=graph)
         x = torch.rand(B, 784, device="cuda") * 2 - 1
         y = torch.randint(0, 10, (B,), device="cuda")
 
@@ -260,7 +262,8 @@ def latent_extras(steps: int = 200, warmup: int = 20):
         lv = loss.item()
         if not (lv == lv) or lv > 1e3:
             raise SystemExit(f"latent training diverged in the benchmark: loss {lv}")
-        out[f"train_B{B}"] = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4)}
+        out[f"train_B{B}" + ("_graph" if graph else "")] = {"samples_per_s": round(B * steps / dt, 1),
+                                                            "ms_per_step": round(dt / steps * 1e3, 4)}
     model.eval()
     y16 = torch.randint(0, 10, (16,), device="cuda")
     torch.cuda.synchronize()

@@ -99,6 +99,13 @@ int tdx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, tdx_stream_t stream);
 
+/* The same update with the step-dependent scalars in device memory, for a training step captured
+ * in a HIP graph: hyper[0] = lr / (1 - beta1^step), hyper[1] = 1 / sqrt(1 - beta2^step),
+ * hyper[2] = grad_scale (the host refreshes the three floats before each replay). */
+int tdx_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      int64_t n, const float* hyper, float beta1, float beta2, float eps,
+                      tdx_stream_t stream);
+
 /* ---- building blocks (exported for unit tests and re-use) --------------- */
 
 /* OIHW (Cout,Cin,3,3) -> forward pack [Cout][9][Cin] and dgrad pack

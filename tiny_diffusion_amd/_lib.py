@@ -87,6 +87,7 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_bilinear_ac_bwd": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, _ptr]),
+    "tdx_adam_step_dev": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr, C.c_float, C.c_float, C.c_float, _ptr]),
     "tdx_step_begin": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, _ptr]),
     "tdx_linear_fwd": (C.c_int, [_ptr, C.c_int, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_linear_bwd": (C.c_int, [_ptr, C.c_int, _ptr, C.c_int, _ptr, _ptr, C.c_int, _ptr, _ptr, C.c_int, C.c_int,

@@ -289,6 +289,34 @@ extern "C" int tdx_adam_step(float* param, const float* grad, float* exp_avg, fl
   return 0;
 }
 
+// Same update with the step-dependent scalars read from device memory, so the launch can sit in a
+// HIP graph that is replayed every step: hyper = {lr/bc1, 1/sqrt(bc2), grad_scale}.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                const float* __restrict__ hyper, float b1, float b2, float eps) {
+  const float lr_bc1 = hyper[0], inv_sqrt_bc2 = hyper[1], gs = hyper[2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gs;
+    float mi = m[i] * b1 + (1.0f - b1) * gi;
+    float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - lr_bc1 * (mi / denom);
+  }
+}
+
+extern "C" int tdx_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                 int64_t n, const float* hyper, float beta1, float beta2, float eps,
+                                 tdx_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return TDX_E_BADARG;
+  adam_dev_kernel<<<ew_grid(n, 256), 256, 0, to_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, n, hyper,
+                                                                 beta1, beta2, eps);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 // -------------------------------------------------------------------- probes
 // fp32 MFMA peak: 4 independent 32x32x2 accumulator chains per wave, 4 waves per block.
 __global__ void __launch_bounds__(256) probe_mfma_kernel(float* out, int iters) {

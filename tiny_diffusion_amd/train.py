@@ -105,7 +105,7 @@ class TrainStep:
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None,
                  max_grad_norm: Optional[float] = None, cosine_T_max: Optional[int] = None,
-                 cosine_eta_min: float = 0.0):
+                 cosine_eta_min: float = 0.0, use_graph: bool = False):
         self.model = model
         # CosineAnnealingLR(optimizer, T_max, eta_min) stepped after every optimizer step
         self.base_lr, self.cosine_T_max, self.cosine_eta_min = lr, cosine_T_max, cosine_eta_min
@@ -125,6 +125,16 @@ class TrainStep:
         self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
         self.world = self.reducer.world
         self.comm = None  # communication stream (created on first use when there is a collective)
+        # use_graph: capture the whole step (randint, q_sample, forward, loss, backward, clip, Adam)
+        # into one HIP graph and replay it.  Single rank, noise and t drawn by torch inside the
+        # graph; step-dependent scalars (lr, Adam bias corrections) live in a 3-float device tensor
+        # refreshed before each replay.  Measured on MI355X it buys little: the small-batch steps
+        # are bound by the GPU-side cost of ~100-170 tiny dependent kernels, not by host launches
+        # (LAION B=8: 2.18 -> 2.05 ms/step; latent MLP B=128: 0.62 -> 0.68), so it is off by default.
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+        self._hyper = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ setup
@@ -159,6 +169,50 @@ class TrainStep:
         """One optimisation step on the local shard ``x_0`` (B,1,28,28) - or (B,4,32,32)
         latents with ``y`` = text embeddings (B,768) for the LAION model; returns the
         (device, not synchronised) loss tensor."""
+        m, fp = self.model, self.diffusion
+        B = x_0.shape[0]
+        dev = x_0.device
+        if (self.use_graph and t is None and noise is None and self.philox_seed is None and self.world == 1
+                and not self.reducer.force):
+            return self._graph_step(x_0, y)
+        return self._eager_step(x_0, y, t, noise)
+
+    def _adam_hyper(self, gscale: float):
+        bc1 = 1.0 - self.betas[0] ** self.step_count
+        bc2 = 1.0 - self.betas[1] ** self.step_count
+        return [self.lr / bc1, 1.0 / math.sqrt(bc2), gscale]
+
+    def _graph_step(self, x_0, y):
+        m = self.model
+        dev = x_0.device
+        key = (tuple(x_0.shape), None if y is None else (tuple(y.shape), y.dtype), m.training)
+        if key != self._graph_key:
+            if self._graph_key is None or self._graph_key[1:] != ("warm",) + key:
+                # first step with these shapes runs eagerly (creates the plan, first-launch set-up);
+                # the next one captures
+                self._graph = None
+                self._graph_key = ("pending", "warm") + key
+                return self._eager_step(x_0, y, None, None)
+            self._gx0 = x_0.detach().clone().contiguous().float()
+            self._gy = None if y is None else y.detach().clone().contiguous()
+            self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._eager_step(self._gx0, self._gy, None, None, hyper=self._hyper)
+            self.step_count -= 1  # capture ran the host bookkeeping once without executing anything
+            self._graph, self._graph_key = g, key
+        self._gx0.copy_(x_0)
+        if y is not None:
+            self._gy.copy_(y)
+        self.step_count += 1
+        self._hyper.copy_(torch.tensor(self._adam_hyper(1.0), dtype=torch.float32))
+        self._graph.replay()
+        m._buf_epoch += 1  # BN running statistics changed on the device (invalidates inference packs)
+        if self.cosine_T_max is not None:
+            self.lr = cosine_annealing_lr(self.step_count, self.base_lr, self.cosine_T_max, self.cosine_eta_min)
+        return self.loss
+
+    def _eager_step(self, x_0, y, t, noise, hyper=None):
         m, fp = self.model, self.diffusion
         B = x_0.shape[0]
         dev = x_0.device
@@ -198,6 +252,12 @@ class TrainStep:
             total = torch.linalg.vector_norm(self.flat_grad) * gscale
             self.flat_grad.mul_((self.max_grad_norm / (total + 1e-6)).clamp(max=1.0))
         self.step_count += 1
+        if hyper is not None:  # being captured: scalars come from device memory at replay time
+            check(lib.tdx_adam_step_dev(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+                                        self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_param.numel(),
+                                        hyper.data_ptr(), self.betas[0], self.betas[1], self.eps, st),
+                  "tdx_adam_step_dev")
+            return self.loss
         check(lib.tdx_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                 self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
                                 self.betas[1], self.eps, self.step_count, gscale, st),
