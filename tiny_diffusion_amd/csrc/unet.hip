@@ -202,7 +202,13 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   (void)hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&u->ev_pack, hipEventDisableTiming);
-  e = hipStreamCreateWithFlags(&u->side2_own, hipStreamNonBlocking);
+  // Low priority like `side`, and not only for scheduling: ROCm multiplexes all streams of one
+  // priority level onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default).  A normal-priority
+  // third stream can land on the caller's queue, and its waits on the wgrad stream then block the
+  // main chain (measured with a communication stream + RCCL's stream also alive: the step went
+  // from 16.3 to 18.1 ms, convolutions fully serialised; with this stream at low priority the
+  // same configuration runs at 16.7 ms).  The low-priority streams have their own queues.
+  e = hipStreamCreateWithPriority(&u->side2_own, hipStreamNonBlocking, lo);
   if (e != hipSuccess) return (int)e;
   u->side = u->side_own;
   u->side2 = u->side2_own;
