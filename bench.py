@@ -371,9 +371,12 @@ def main():
                 value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             res["cpu_baseline"] = cpu_baseline()
             model.eval()
+            s16, s64 = sample_latency(model, fp, 16), sample_latency(model, fp, 64)
+            fwd = TRAIN_FLOP_PER_IMAGE / 3.0  # forward FLOPs per image and step
             res["sample"] = {"unit": "s per 1000-step chain (HIP-graph replay, in-kernel Philox noise)",
-                             "n16": round(sample_latency(model, fp, 16), 3),
-                             "n64": round(sample_latency(model, fp, 64), 3)}
+                             "n16": round(s16, 3), "n64": round(s64, 3),
+                             "n16_tflops": round(16 * 1000 * fwd / s16 / 1e12, 1),
+                             "n64_tflops": round(64 * 1000 * fwd / s64 / 1e12, 1)}
             res["laion_unet"] = laion_extras()
             res["latent_mlp"] = latent_extras()
         print(json.dumps(res))

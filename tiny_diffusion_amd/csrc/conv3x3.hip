@@ -609,26 +609,36 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
   dma_tile(0, 0);
   __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of a barrier)
   int cur = 0;
+  // Fragment registers are double-buffered: the four ds_read_b128 of k-step ks+1 are issued BEFORE
+  // the 16 MFMAs of k-step ks (hipcc otherwise re-uses the same registers and places the reads
+  // after the MFMAs that consume them, exposing the LDS latency once per k-step: ~10 % of the loop).
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frags = [&](int buf, int ks, int slot) {
+    const float* Ab = As + buf * BM * BK + (wm * WTM + l31) * BK;
+    const float* Bb = Bs + buf * BN * BK + (wn * WTN + l31) * BK;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+      af[slot][im] = *reinterpret_cast<const f32x4*>(Ab + im * 32 * BK + frag_pos[ks]);
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+      bf[slot][in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BK + frag_pos[ks]);
+  };
   for (int kt = 0; kt < nk; ++kt) {
     dma_tile(kt + 1, cur ^ 1);  // clamped at the end: a redundant copy of the last tile, never read
-    const float* Ab = As + cur * BM * BK + (wm * WTM + l31) * BK;
-    const float* Bb = Bs + cur * BN * BK + (wn * WTN + l31) * BK;
+    read_frags(cur, 0, 0);
 #pragma unroll
     for (int ks = 0; ks < BK / 8; ++ks) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-        af[im] = *reinterpret_cast<const f32x4*>(Ab + im * 32 * BK + frag_pos[ks]);
-#pragma unroll
-      for (int in = 0; in < TN; ++in)
-        bf[in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BK + frag_pos[ks]);
+      if (ks + 1 < BK / 8) {
+        read_frags(cur, ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);  // fence: the reads are issued before this k-step's MFMAs
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int im = 0; im < TM; ++im)
 #pragma unroll
           for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][im][j], bf[ks & 1][in][j], acc[im][in], 0, 0, 0);
     }
     __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading tile kt
     cur ^= 1;
