@@ -246,6 +246,32 @@ int tdx_vae_reparameterize(const float* mu, const float* logvar, const float* ep
 int tdx_vae_decode(const float* z, const void* const* params, float* out, float* workspace,
                    int batch, int input_dim, int hidden_dim, int latent_dim, tdx_stream_t stream);
 
+/* ---- row / elementwise blocks of the "transformer" noise model (diffusion_transformer.py:16-107;
+ * its attention runs on a length-1 sequence, i.e. it is out_proj(v_proj(x))) -------------------
+ * LayerNorm over the last dimension N (N % 64 == 0, N <= 1024), eps as nn.LayerNorm (1e-5);
+ * mean / rstd (M,) are saved for the backward. */
+int tdx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
+                      float* mean, float* rstd, int M, int N, float eps, tdx_stream_t stream);
+/* gx (M,N), dgamma, dbeta (N,); gx or the pair dgamma/dbeta may be NULL. */
+int tdx_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, float* gx, float* dgamma, float* dbeta, int M, int N,
+                      tdx_stream_t stream);
+/* kind 0: SiLU, 1: GELU (erf form, the nn.GELU default). */
+int tdx_act_fwd(const float* x, float* out, int64_t n, int kind, tdx_stream_t stream);
+int tdx_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int kind, tdx_stream_t stream);
+/* out = x * keep / (1-p), one Philox Bernoulli draw per `group` consecutive elements (group 1 =
+ * nn.Dropout; group = head_dim = dropout of a head's single attention weight).  The backward is
+ * the same call on the gradient with the same (seed, offset). */
+int tdx_dropout(const float* x, float* out, int64_t n, int group, float p, uint64_t seed,
+                uint64_t offset, tdx_stream_t stream);
+/* out[i] = a[i] + b[i % b_period] (b_period 0: same shape). */
+int tdx_add(const float* a, const float* b, float* out, int64_t n, int64_t b_period, tdx_stream_t stream);
+/* nn.Embedding forward (gather of rows) and backward (deterministic scatter-sum). */
+int tdx_embedding_fwd(const float* weight, const int64_t* idx, float* out, int M, int N,
+                      tdx_stream_t stream);
+int tdx_embedding_bwd(const float* g, const int64_t* idx, float* dweight, int M, int N, int num,
+                      tdx_stream_t stream);
+
 typedef struct tdx_unet tdx_unet;
 
 /* num_classes == 0: unconditional (diffusion.py); > 0: class-conditional. */

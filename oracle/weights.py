@@ -299,3 +299,33 @@ def key_shapes_vae(input_dim: int = 784, hidden_dim: int = 400, latent_dim: int 
 
 def make_state_dict_vae(seed: int = 0):
     return _fill(np.random.RandomState(seed), key_shapes_vae())
+
+
+# --------------------------------------------------------------------------
+# diffusion_transformer.py NoiseModel: 4 post-norm blocks on a length-1 sequence
+# --------------------------------------------------------------------------
+def key_shapes_transformer(time_dim: int = 256, num_classes: int = 10, latent_dim: int = 20, num_layers: int = 4):
+    """Ordered (key, shape, kind) == state_dict() of diffusion_transformer.NoiseModel (38-80)."""
+    D = time_dim
+    out = [("pos_encoding", (1, 1, D), "emb")]   # nn.Parameter registered on the module itself comes first
+    for name, cin, cout in (("time_embedding.0", 1, D), ("time_embedding.2", D, D)):
+        out += [(f"{name}.weight", (cout, cin), "lin_w"), (f"{name}.bias", (cout,), "bias")]
+    out.append(("class_embedding.weight", (num_classes, D), "emb"))
+    out += [("input_proj.weight", (D, latent_dim), "lin_w"), ("input_proj.bias", (D,), "bias")]
+    for i in range(num_layers):
+        p = f"transformer_blocks.{i}"
+        out += [(f"{p}.attention.in_proj_weight", (3 * D, D), "lin_w"), (f"{p}.attention.in_proj_bias", (3 * D,), "bias"),
+                (f"{p}.attention.out_proj.weight", (D, D), "lin_w"), (f"{p}.attention.out_proj.bias", (D,), "bias"),
+                (f"{p}.norm1.weight", (D,), "bn_w"), (f"{p}.norm1.bias", (D,), "bn_b"),
+                (f"{p}.ff.0.weight", (4 * D, D), "lin_w"), (f"{p}.ff.0.bias", (4 * D,), "bias"),
+                (f"{p}.ff.2.weight", (D, 4 * D), "lin_w"), (f"{p}.ff.2.bias", (D,), "bias"),
+                (f"{p}.norm2.weight", (D,), "bn_w"), (f"{p}.norm2.bias", (D,), "bn_b")]
+    out += [("final_layer.0.weight", (D,), "bn_w"), ("final_layer.0.bias", (D,), "bn_b"),
+            ("final_layer.1.weight", (latent_dim, D), "lin_w"), ("final_layer.1.bias", (latent_dim,), "bias")]
+    return out
+
+
+def make_state_dict_transformer(seed: int = 0):
+    sd = _fill(np.random.RandomState(seed), key_shapes_transformer())
+    sd["pos_encoding"] = sd["pos_encoding"] * 0.5
+    return sd

@@ -96,6 +96,14 @@ _SIGS = {
     "tdx_vae_encode": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_vae_reparameterize": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, _ptr]),
     "tdx_vae_decode": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_layernorm_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_float, _ptr]),
+    "tdx_layernorm_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_act_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr]),
+    "tdx_act_bwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int, _ptr]),
+    "tdx_dropout": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint64, _ptr]),
+    "tdx_add": (C.c_int, [_ptr, _ptr, _ptr, C.c_int64, C.c_int64, _ptr]),
+    "tdx_embedding_fwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_embedding_bwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_unet_create": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int]),
     "tdx_unet_create_ex": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int]),
     "tdx_unet_destroy": (C.c_int, [_ptr]),

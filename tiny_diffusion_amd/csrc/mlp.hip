@@ -725,3 +725,228 @@ extern "C" int tdx_vae_decode(const float* z, const void* const* params, float* 
   return linear_fwd(workspace, hidden_dim, P[2], P[3], out, input_dim, batch, input_dim, hidden_dim, 2, nullptr,
                     nullptr, nullptr, 0, st);
 }
+
+// ------------------------------------------------------------------------------------------
+// Building blocks of the "transformer" noise model of diffusion_transformer.py:16-107 (sequence
+// length 1: attention(x) == out_proj(v_proj(x)); LayerNorm, GELU, SiLU, dropout, residual adds).
+// All latency-bound elementwise / row kernels on (B, 256..1024) activations.
+namespace {
+
+// one wave per row; a lane keeps its N/64 values in registers (N % 64 == 0, N <= 1024)
+template <int PER>
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, float* __restrict__ out, float* __restrict__ mean_out,
+                     float* __restrict__ rstd_out, int M, float eps) {
+  constexpr int N = PER * 64;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { v[i] = x[(size_t)row * N + lane + 64 * i]; s += v[i]; }
+  const float mean = wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    out[(size_t)row * N + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// gx = rstd * (a - mean(a) - xhat * mean(a * xhat)),  a = gy * gamma
+template <int PER>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ gamma,
+                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ gx,
+                     int M) {
+  constexpr int N = PER * 64;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float mu = mean[row], rs = rstd[row];
+  float a[PER], xh[PER];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    xh[i] = (x[(size_t)row * N + c] - mu) * rs;
+    a[i] = gy[(size_t)row * N + c] * gamma[c];
+    s1 += a[i];
+    s2 = fmaf(a[i], xh[i], s2);
+  }
+  s1 = wave_sum(s1) / (float)N;
+  s2 = wave_sum(s2) / (float)N;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) gx[(size_t)row * N + lane + 64 * i] = rs * (a[i] - s1 - xh[i] * s2);
+}
+
+// dgamma[c] = sum_rows gy * xhat, dbeta[c] = sum_rows gy; block = 32 columns x 8 row slices
+__global__ void __launch_bounds__(256)
+layernorm_param_grad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int N) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  float sg = 0.f, sb = 0.f;
+  if (c < N)
+    for (int m = sl; m < M; m += 8) {
+      const float g = gy[(size_t)m * N + c];
+      sg = fmaf(g, (x[(size_t)m * N + c] - mean[m]) * rstd[m], sg);
+      sb += g;
+    }
+  red[0][sl][cl] = sg;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0 && c < N) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a += red[0][k][cl]; b += red[1][k][cl]; }
+    dgamma[c] = a;
+    dbeta[c] = b;
+  }
+}
+
+__device__ inline float act_f(float x, int kind) {
+  if (kind == 0) return x / (1.0f + expf(-x));                      // SiLU
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));     // GELU (erf form, nn.GELU default)
+}
+__device__ inline float act_grad_f(float x, int kind) {
+  if (kind == 0) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+  }
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = act_f(x[i], kind);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                               float* __restrict__ gx, int64_t n, int kind) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gx[i] = gy[i] * act_grad_f(x[i], kind);
+}
+
+// out = x * keep / (1 - p); one Bernoulli(1-p) draw per `group` consecutive elements
+// (group = 1: nn.Dropout; group = head_dim: dropout of the single attention weight of a head)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, int group,
+                               float p, float scale, uint64_t seed, uint64_t offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t gidx = (uint64_t)(i / group);
+  const Philox4 r = philox4x32_10(gidx >> 2, offset, seed);
+  const float u = ((float)r.v[gidx & 3] + 0.5f) * 2.3283064365386963e-10f;
+  out[i] = u < p ? 0.f : x[i] * scale;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           int64_t n, int64_t period) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[period ? i % period : i];
+}
+
+__global__ void embedding_fwd_kernel(const float* __restrict__ w, const int64_t* __restrict__ idx,
+                                     float* __restrict__ out, int M, int N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)M * N) out[i] = w[(size_t)idx[i / N] * N + i % N];
+}
+// dE[c][j] = sum_{m : idx[m] == c} g[m][j]   (fixed order: deterministic)
+__global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                     float* __restrict__ dw, int M, int N, int num) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num * N) return;
+  const int c = i / N, j = i - c * N;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m)
+    if ((int)idx[m] == c) s += g[(size_t)m * N + j];
+  dw[i] = s;
+}
+
+}  // namespace
+
+#define TDX_LN_DISPATCH(KERNEL, ...)                                              \
+  switch (N / 64) {                                                               \
+    case 1: KERNEL<1><<<cdiv(M, 4), 256, 0, st>>>(__VA_ARGS__); break;            \
+    case 2: KERNEL<2><<<cdiv(M, 4), 256, 0, st>>>(__VA_ARGS__); break;            \
+    case 4: KERNEL<4><<<cdiv(M, 4), 256, 0, st>>>(__VA_ARGS__); break;            \
+    case 8: KERNEL<8><<<cdiv(M, 4), 256, 0, st>>>(__VA_ARGS__); break;            \
+    case 16: KERNEL<16><<<cdiv(M, 4), 256, 0, st>>>(__VA_ARGS__); break;          \
+    default: return TDX_E_SHAPE;                                                  \
+  }
+
+extern "C" int tdx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
+                                 float* mean, float* rstd, int M, int N, float eps, tdx_stream_t stream) {
+  if (!x || !gamma || !beta || !out || !mean || !rstd || M <= 0 || N <= 0) return TDX_E_BADARG;
+  if (N % 64) return TDX_E_SHAPE;
+  hipStream_t st = to_stream(stream);
+  TDX_LN_DISPATCH(layernorm_fwd_kernel, x, gamma, beta, out, mean, rstd, M, eps)
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, float* gx, float* dgamma, float* dbeta, int M, int N,
+                                 tdx_stream_t stream) {
+  if (!gy || !x || !gamma || !mean || !rstd || M <= 0 || N <= 0) return TDX_E_BADARG;
+  if (N % 64) return TDX_E_SHAPE;
+  hipStream_t st = to_stream(stream);
+  if (gx) {
+    TDX_LN_DISPATCH(layernorm_bwd_kernel, gy, x, gamma, mean, rstd, gx, M)
+    TDX_CHECK_LAUNCH();
+  }
+  if (dgamma && dbeta) {
+    layernorm_param_grad_kernel<<<cdiv(N, 32), 256, 0, st>>>(gy, x, mean, rstd, dgamma, dbeta, M, N);
+    TDX_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int tdx_act_fwd(const float* x, float* out, int64_t n, int kind, tdx_stream_t stream) {
+  if (!x || !out || n <= 0 || kind < 0 || kind > 1) return TDX_E_BADARG;
+  act_fwd_kernel<<<cdiv(n, 256), 256, 0, to_stream(stream)>>>(x, out, n, kind);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_act_bwd(const float* gy, const float* x, float* gx, int64_t n, int kind, tdx_stream_t stream) {
+  if (!gy || !x || !gx || n <= 0 || kind < 0 || kind > 1) return TDX_E_BADARG;
+  act_bwd_kernel<<<cdiv(n, 256), 256, 0, to_stream(stream)>>>(gy, x, gx, n, kind);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_dropout(const float* x, float* out, int64_t n, int group, float p, uint64_t seed,
+                           uint64_t offset, tdx_stream_t stream) {
+  if (!x || !out || n <= 0 || group <= 0 || !(p >= 0.f && p < 1.f)) return TDX_E_BADARG;
+  dropout_kernel<<<cdiv(n, 256), 256, 0, to_stream(stream)>>>(x, out, n, group, p, 1.0f / (1.0f - p), seed, offset);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_add(const float* a, const float* b, float* out, int64_t n, int64_t b_period, tdx_stream_t stream) {
+  if (!a || !b || !out || n <= 0 || b_period < 0) return TDX_E_BADARG;
+  add_kernel<<<cdiv(n, 256), 256, 0, to_stream(stream)>>>(a, b, out, n, b_period);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_embedding_fwd(const float* weight, const int64_t* idx, float* out, int M, int N,
+                                 tdx_stream_t stream) {
+  if (!weight || !idx || !out || M <= 0 || N <= 0) return TDX_E_BADARG;
+  embedding_fwd_kernel<<<cdiv((int64_t)M * N, 256), 256, 0, to_stream(stream)>>>(weight, idx, out, M, N);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_embedding_bwd(const float* g, const int64_t* idx, float* dweight, int M, int N, int num,
+                                 tdx_stream_t stream) {
+  if (!g || !idx || !dweight || M <= 0 || N <= 0 || num <= 0) return TDX_E_BADARG;
+  embedding_bwd_kernel<<<cdiv((int64_t)num * N, 256), 256, 0, to_stream(stream)>>>(g, idx, dweight, M, N, num);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}

@@ -418,9 +418,51 @@ def latent_fixtures():
     print("latent_B32 loss train/eval", d["loss_train"], d["loss_eval"])
 
 
+def transformer_fixtures():
+    """diffusion_transformer.py NoiseModel: eval-mode forward of the default model (dropout 0.05,
+    inactive in eval) and forward + gradients of a dropout=0.0 model in train mode (train-mode
+    dropout draws from torch's generator: not reproducible outside the reference)."""
+    from oracle.weights import make_state_dict_transformer
+
+    load_reference_latent()   # registers the torchvision / wandb / vae stubs
+    spec = importlib.util.spec_from_file_location("ref_diffusion_transformer",
+                                                  os.path.join(REF, "diffusion_transformer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sd = make_state_dict_transformer(0)
+    rs = np.random.RandomState(31337)
+    B = 16
+    z_t = rs.standard_normal((B, 20)).astype(np.float32)
+    noise = rs.standard_normal((B, 20)).astype(np.float32)
+    t = rs.randint(0, 1000, size=(B,)).astype(np.int64); t[0], t[1] = 0, 999
+    y = rs.randint(0, 10, size=(B,)).astype(np.int64)
+    zt, nt, tt, yt = (torch.from_numpy(a) for a in (z_t, noise, t, y))
+    d = dict(z_t=z_t, noise=noise, t=t, y=y)
+    m = mod.NoiseModel(); m.load_state_dict(sd, strict=True); m.eval()
+    with torch.no_grad():
+        d["eps_eval"] = m(zt, tt, yt).numpy()
+    m0 = mod.NoiseModel(dropout=0.0); m0.load_state_dict(sd, strict=True); m0.train()
+    eps = m0(zt, tt, yt)
+    loss = F.mse_loss(eps, nt); loss.backward()
+    d["eps_train_nodrop"] = eps.detach().numpy(); d["loss"] = np.float64(loss.item())
+    for k, p in m0.named_parameters():
+        g = p.grad.detach().contiguous().view(-1); kk = k.replace(".", "__")
+        d[f"gnorm__{kk}"] = np.float64(g.double().norm().item())
+        d[f"ghead__{kk}"] = g[:128].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "transformer_B16.npz"), **d)
+    with open(os.path.join(OUT, "weights.sha256"), "a") as f:
+        f.write(f"transformer seed0 {state_dict_sha256(sd)}\n")
+        torch.manual_seed(0)
+        f.write(f"init transformer_seed0 {state_dict_sha256(mod.NoiseModel().state_dict())}\n")
+    print("transformer_B16 loss", d["loss"])
+
+
 def main():
     if "--latent-only" in sys.argv:
         latent_fixtures()
+        return
+    if "--transformer-only" in sys.argv:
+        transformer_fixtures()
         return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -448,6 +490,7 @@ def main():
     sample_fixture(unc, False, 1000, 4, keep=[999, 750, 500, 250, 1, 0])
     laion_fixtures(load_reference("conditional_diffusion_laion.py"))
     latent_fixtures()
+    transformer_fixtures()
 
 
 if __name__ == "__main__":
