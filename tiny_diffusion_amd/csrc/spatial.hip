@@ -195,6 +195,49 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* _
   }
 }
 
+// Both halves of a decoder input in ONE launch (inference / sampling, where every launch is ~5 us
+// of a ~550 us step): channels [0, CA) = resize(A), channels [CA, CA+CB) = resize(Bsrc + addend).
+struct ResizeSrc {
+  const float* in; const float* addend; int Hi, Wi, C; float sch, scw;
+};
+__global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __restrict__ out, int B, int Ho,
+                                         int Wo) {
+  const int ocs = A.C + Bs.C, c4n = ocs / 4;
+  const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int oc = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const bool first = oc < A.C;
+    const ResizeSrc& S = first ? A : Bs;
+    const int c = first ? oc : oc - A.C;
+    const AxisTap th = axis_tap(oh, S.sch, S.Hi), tw = axis_tap(ow, S.scw, S.Wi);
+    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S.addend) ad = *reinterpret_cast<const float4*>(S.addend + (int64_t)b * S.C + c);
+    const float* base = S.in + (int64_t)b * S.Hi * S.Wi * S.C + c;
+    auto ld = [&](int h, int w) {
+      float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)h * S.Wi + w) * S.C);
+      v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+      return v;
+    };
+    const float4 v00 = ld(th.i0, tw.i0), v01 = ld(th.i0, tw.i1);
+    const float4 v10 = ld(th.i1, tw.i0), v11 = ld(th.i1, tw.i1);
+    float4 o;
+#define LERP(k)                                            \
+    {                                                      \
+      const float top = tw.l0 * v00.k + tw.l1 * v01.k;     \
+      const float bot = tw.l0 * v10.k + tw.l1 * v11.k;     \
+      o.k = th.l0 * top + th.l1 * bot;                     \
+    }
+    LERP(x) LERP(y) LERP(z) LERP(w)
+#undef LERP
+    *reinterpret_cast<float4*>(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + oc) = o;
+  }
+}
+
 static inline float ac_scale(int n_in, int n_out) {
   return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
 }
@@ -213,6 +256,17 @@ extern "C" int tdx_bilinear_ac_fwd(const float* in, const float* scale, const fl
   else
     bilinear_fwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
         in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
+                          int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st) {
+  if (!a || !b || !out || Ca % 4 || Cb % 4) return TDX_E_BADARG;
+  ResizeSrc A{a, nullptr, Ha, Wa, Ca, ac_scale(Ha, Ho), ac_scale(Wa, Wo)};
+  ResizeSrc Bs{b, b_addend, Hb, Wb, Cb, ac_scale(Hb, Ho), ac_scale(Wb, Wo)};
+  const int64_t n = (int64_t)B * Ho * Wo * ((Ca + Cb) / 4);
+  bilinear_pair_fwd_kernel<<<ew_grid(n), 256, 0, st>>>(A, Bs, out, B, Ho, Wo);
   TDX_CHECK_LAUNCH();
   return 0;
 }

@@ -512,13 +512,14 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const UnitDef& da = S.units[ua];
     const UnitDef& dp = S.units[prev];
     const int hw = da.hw, c_up = dp.cout, c_skip = S.skip_ch[skip_k];
-    RC(tdx_bilinear_ac_fwd(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
-                           c_up, da.cin, 0, stream));
-    if (infer)
-      RC(tdx_bilinear_ac_fwd(ws + L.Y[skip_u], sc(skip_u), sh(skip_u), ws + L.tp[skip_k], ws + L.cat[k], B,
-                             S.enc_hw[skip_k], S.enc_hw[skip_k], hw, hw, c_skip, da.cin, c_up, stream));
-    else
-      TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[skip_k], 0));  // written during the encoder
+    if (infer) {  // both halves in one launch (post-activation tensors: nothing to apply on load)
+      RC(tdx_bilinear_pair_fwd(ws + L.Y[prev], dp.hw, dp.hw, c_up, ws + L.Y[skip_u], ws + L.tp[skip_k],
+                               S.enc_hw[skip_k], S.enc_hw[skip_k], c_skip, ws + L.cat[k], B, hw, hw, st));
+    } else {
+      RC(tdx_bilinear_ac_fwd(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
+                             c_up, da.cin, 0, stream));
+      TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[skip_k], 0));  // skip half: written during the encoder
+    }
     RC(run_unit(ua, ws + L.cat[k]));
     RC(run_unit(ub, ws + L.Y[ua]));
   }
