@@ -209,7 +209,13 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   // from 16.3 to 18.1 ms, convolutions fully serialised; with this stream at low priority the
   // same configuration runs at 16.7 ms).  The low-priority streams have their own queues.
   e = hipStreamCreateWithPriority(&u->side2_own, hipStreamNonBlocking, lo);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(u->side_own);
+    (void)hipFree(u->wpack);
+    (void)hipFree(u->infer_ss);
+    delete u;
+    return (int)e;
+  }
   u->side = u->side_own;
   u->side2 = u->side2_own;
   for (int i = 0; i < 3; ++i) {
