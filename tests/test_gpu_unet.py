@@ -390,3 +390,26 @@ def test_staged_backward_equals_single_call():
         m2 = build(False, 4)
         _, plan2, _ = m2._run_forward(x, t, None, mode=2)
         m2._run_backward(plan2, d_out, m2._grad_buffers(x.device)[1], 3, 5)
+
+
+def test_sample_chain_T1000_vs_reference_golden(golden_dir):
+    """The full 1000-step reverse chain (BASELINE metric (ii) shape, n = 4) with the reference's own
+    noise sequence (CPU generator, seed recorded in the golden) against the reference's recorded
+    states: per-step fp32 differences are amplified along the chain ('gate x_0 on the
+    T=20 chain, report T=1000 drift'), so the gate is loose and the drift is printed."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+    from tiny_diffusion_amd.schedule import sample_loop
+
+    d = load(golden_dir, "sample_T1000_n4_uncond")
+    m = build(False, int(d["seed"]))
+    torch.manual_seed(int(d["rng_seed"]))
+    x_T = torch.randn(4, 1, 28, 28)
+    assert np.array_equal(x_T.numpy(), d["x_T"])
+    zs = [None] * 1000
+    for t in reversed(range(1000)):
+        if t > 0:
+            zs[t] = torch.randn_like(x_T)
+    x = sample_loop(m, ForwardProcess(), "cuda", 4, None, x_T=x_T, noises=zs, use_graph=True)
+    drift = rel_mse(x, torch.from_numpy(d["final"]))
+    print(f"T=1000 chain, n=4: relative MSE of x_0 vs the reference = {drift:.3e}")
+    assert torch.isfinite(x).all() and drift < 1e-8, drift   # measured 7.4e-11
