@@ -64,6 +64,7 @@ int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const flo
 // tuning knob "materialize": 1 = the activation feeding the second convolution of a stage is
 // written out (post BN+ReLU) so that convolution and its wgrad run on the LDS-DMA kernels
 extern int g_tdx_materialize;
+extern int g_tdx_time_stage;
 // inference: both halves of a decoder's concatenated input (resize(a) | resize(b + b_addend)) in one launch
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
                           int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st);

@@ -129,6 +129,7 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+int g_tdx_time_stage = 6;  // backward stage after which the time/class path runs (6 or 14)
 int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
 
 struct tdx_unet {
@@ -691,6 +692,17 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     g_next = gup;
     return 0;
   };
+  // the time / class path only needs the three pixel sums, which the third stream produced itself
+  // (dec_level_bwd): it runs there, in order, as soon as the last of them is enqueued (stage 6),
+  // hidden under the encoder's backward instead of trailing the step
+  auto time_path_bwd = [&](hipStream_t st) -> int {
+    TDX_HIP(hipEventRecord(u->ev_fork, st));
+    TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
+    return tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
+                              u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
+                              P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2);
+  };
   // first unit of an encoder level below the top, or the bottleneck (units 6, 4, 2): its input is a
   // pooled tensor; route the gradient through the max-pool and add the skip-path gradient
   auto pooled_unit_bwd = [&](int ui, int k) -> int {  // k: encoder level whose output was pooled (2, 1, 0)
@@ -729,7 +741,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 3: RC(plain_unit_bwd(10, ws + L.Y[9])); break;
       case 4: RC(dec_level_bwd(1)); break;
       case 5: RC(plain_unit_bwd(8, ws + L.Y[7])); break;
-      case 6: RC(dec_level_bwd(0)); break;
+      case 6:
+        RC(dec_level_bwd(0));
+        if (g_tdx_time_stage == 6) RC(time_path_bwd(st));
+        break;
       case 7: RC(pooled_unit_bwd(6, 2)); break;
       case 8: RC(plain_unit_bwd(5, ws + L.Y[4])); break;
       case 9: RC(pooled_unit_bwd(4, 1)); break;
@@ -738,16 +753,9 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 12: RC(plain_unit_bwd(1, ws + L.Y[0])); break;
       case 13: RC(plain_unit_bwd(0, ws + L.x0)); break;  // g(x0)
       case 14:
-        // the time / class path only needs the three pixel sums (third stream, in order there):
-        // beside initial_conv's weight gradient and the last wgrad GEMMs
-        TDX_HIP(hipEventRecord(u->ev_fork, st));
-        TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
+        if (g_tdx_time_stage != 6) RC(time_path_bwd(st));
         RC(tdx_initial_conv_wgrad(ws + L.x, g_next, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
                                   S.hw0, S.in_ch, S.x0_real, st));
-        RC(tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
-                              u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
-                              P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2));
         break;
     }
   }
