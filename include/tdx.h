@@ -65,7 +65,7 @@ int tdx_q_sample_philox(const float* x0, const int64_t* t, const float* sqrt_ac,
                         tdx_stream_t stream);
 
 /* One reverse step, diffusion.py:272-274:
- *   x_out = c1*(x - c2*eps) + sigma*z        (z == NULL means z = 0, the t == 0 branch)
+ *   x_out = c1*(x - c2*eps) + sigma*z        (z == NULL or t == 0: z = 0, diffusion.py:267-270)
  * coef: device table (T,3) of (c1,c2,sigma) = (1/sqrt(alpha), (1-alpha)/sqrt(1-acp), sqrt(beta));
  * t_idx: device pointer to the current step index (int32) so that a captured
  * graph can be replayed for every t.  16 B/element (read x, eps, z; write x). */
@@ -145,6 +145,12 @@ size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin, int cout)
 int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout);
 
+/* dx = d(conv3x3)/d(input) (autograd of diffusion.py:32-95 convolutions): the same implicit GEMM
+ * with the roles of the channels swapped and the taps mirrored.
+ *   dy (B,H,W,cout) NHWC; w_dgrad: the second output of tdx_pack_conv3x3; dx (B,H,W,cin) NHWC. */
+int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
+                      int cin, int cout, tdx_stream_t stream);
+
 /* Weight gradient of the same convolution:
  *   dw_slabs[s][cout][9][cin] partial sums over pixel chunk s (split-K, deterministic)
  * followed by tdx_conv3x3_wgrad_reduce -> OIHW gradient.  `in` may be a pre-BN
@@ -168,6 +174,12 @@ int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_rows, int64_
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* scale, float* shift, float* save_mean, float* save_rstd,
                     int training, tdx_stream_t stream);
+
+/* a = relu(y*scale + shift): the normalised activation written out (BatchNorm2d + ReLU,
+ * diffusion.py:34-35) for consumers that want it materialised; scale/shift from tdx_bn_finalize.
+ *   y, out (rows, C) NHWC rows; C % 4 == 0. */
+int tdx_bn_apply_relu_fwd(const float* y, float* out, int64_t rows, int C, const float* scale,
+                          const float* shift, tdx_stream_t stream);
 
 /* BN+ReLU backward, in place on g (B*H*W, C):
  *   gz = g * [y*scale+shift > 0];  dgamma = sum gz*xhat;  dbeta = sum gz
@@ -318,6 +330,30 @@ int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads
  * so that the gradients of the finished stages are final there.  (The caller orders `stream`
  * after its own compute stream as well.) */
 int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream);
+
+/* The time / class path on its own (diffusion.py:21-25, 105-113, 130-132;
+ * conditional_diffusion.py:31, 121-125): emb = W2 silu(W1 float(t) + b1) + b2 [+ E[y]], then the
+ * three 1x1 projections.  params/grads: TDX_P_COUNT tables (only the TE, CLASS_EMB, TP slots are read /
+ * written).  pre, emb (B,256); t1 (B,128), t2 (B,256), t3 (B,512); y NULL = unconditional.
+ * bwd: g_t1..3 are d(loss)/d(t1..3) (already summed over pixels); scratch 3*B*256 floats. */
+int tdx_time_mlp_fwd(const int64_t* t, const int64_t* y, const void* const* params, float* pre,
+                     float* emb, float* t1, float* t2, float* t3, int batch, tdx_stream_t stream);
+int tdx_time_mlp_bwd(const int64_t* t, const int64_t* y, const void* const* params,
+                     void* const* grads, const float* pre, const float* emb, const float* g_t1,
+                     const float* g_t2, const float* g_t3, float* scratch, int batch,
+                     int num_classes, tdx_stream_t stream);
+
+/* One reverse step x_t -> x_{t-1} of sample() (diffusion.py:259-274), capturable in a HIP graph:
+ *   t = *counter; *counter = t - 1;  eps = eps_theta(x, t[, cond]) in TDX_MODE_INFER;
+ *   x = c1[t] (x - c2[t] eps) + sigma[t] z   in place (z = 0 at t == 0).
+ * z: recorded / host-drawn noise of x's shape, or NULL for in-kernel Philox noise keyed by
+ * (philox_seed, t).  coef: (T,3) table as for tdx_p_sample_step.  t_idx (1 int32), t_vec (batch
+ * int64) and eps (x's shape) are caller scratch.  x has n_elems = batch * per-sample elements. */
+int tdx_unet_eval_step(tdx_unet* u, const void* const* params, void* const* buffers, float* x,
+                       const void* cond, const float* z, const float* coef, int64_t* counter,
+                       int32_t* t_idx, int64_t* t_vec, float* eps, int64_t n_elems,
+                       void* workspace, size_t workspace_bytes, int batch, uint64_t philox_seed,
+                       tdx_stream_t stream);
 
 /* Testing aid: offset (in floats) and element count of a named intermediate inside the
  * workspace after a forward: "x0", "Y0".."Y12", "ss0".."ss12", "e1p", "cat1", "d1a", ... */

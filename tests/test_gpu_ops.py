@@ -419,3 +419,80 @@ def test_u8_gather_normalize_bit_exact(tdx):
     assert torch.equal(key(seen), key(allb))
     with pytest.raises(IndexError):
         ds.batch(torch.tensor([500]).cuda())
+
+
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 14, 128, 256), (2, 28, 64, 128)])
+def test_conv3x3_dgrad_entry(tdx, B, H, cin, cout):
+    """tdx_conv3x3_dgrad (the name SURVEY.md 8(b) lists) against autograd."""
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=21)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(22))
+    y.backward(g)
+    _, wd = _pack(tdx, w)
+    gd = dev(nhwc(g))
+    dx = torch.full((B, H, H, cin), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_dgrad(gd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, H, H, cin, cout, stream()))
+    assert rel_err(nchw(dx), x.grad) < 2e-6
+
+
+def test_bn_apply_relu_fwd_bit_exact(tdx):
+    g = torch.Generator().manual_seed(23)
+    rows, Cc = 5 * 14 * 14, 128
+    y = torch.randn(rows, Cc, generator=g)
+    sc, sh = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g) * 0.3
+    out = torch.full((rows, Cc), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_bn_apply_relu_fwd(dev(y).data_ptr(), out.data_ptr(), rows, Cc, dev(sc).data_ptr(),
+                                            dev(sh).data_ptr(), stream()))
+    ref = torch.relu(torch.addcmul(sh, y, sc))          # one fma per element, as the kernel
+    assert (out.cpu() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    assert tdx.lib.tdx_bn_apply_relu_fwd(None, out.data_ptr(), rows, Cc, None, None, stream()) != 0
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_time_mlp_fwd_bwd(tdx, cond):
+    """Time MLP + class embedding + the three 1x1 projections on their own (diffusion.py:21-25,
+    105-113, 130-132; conditional_diffusion.py:121-125) against torch autograd on the CPU."""
+    from tiny_diffusion_amd.unet import param_slot_names
+
+    B, TD, ncls = 37, 256, 10
+    g = torch.Generator().manual_seed(31 + cond)
+    names = param_slot_names(cond)
+    shapes = {"time_embedding.0.weight": (TD, 1), "time_embedding.0.bias": (TD,),
+              "time_embedding.2.weight": (TD, TD), "time_embedding.2.bias": (TD,),
+              "class_embedding.weight": (ncls, TD),
+              "time_proj1.weight": (128, TD, 1, 1), "time_proj1.bias": (128,),
+              "time_proj2.weight": (256, TD, 1, 1), "time_proj2.bias": (256,),
+              "time_proj3.weight": (512, TD, 1, 1), "time_proj3.bias": (512,)}
+    P = {k: (torch.randn(v, generator=g) * (0.002 if k == "time_embedding.0.weight" else 0.06)).requires_grad_(True)
+         for k, v in shapes.items() if cond or k != "class_embedding.weight"}
+    t = torch.randint(0, 1000, (B,), generator=g)
+    y = torch.randint(0, ncls, (B,), generator=g) if cond else None
+    pre = t.float().unsqueeze(1) @ P["time_embedding.0.weight"].t() + P["time_embedding.0.bias"]
+    emb = F.silu(pre) @ P["time_embedding.2.weight"].t() + P["time_embedding.2.bias"]
+    if cond:
+        emb = emb + P["class_embedding.weight"][y]
+    outs = [emb @ P[f"time_proj{k}.weight"].flatten(1).t() + P[f"time_proj{k}.bias"] for k in (1, 2, 3)]
+    gts = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * gt).sum() for o, gt in zip(outs, gts)).backward()
+
+    pd = {k: dev(v.detach()) for k, v in P.items()}
+    gd = {k: torch.full_like(v, float("nan")) for k, v in pd.items()}
+    ptab = (C.c_void_p * len(names))(*[pd[n].data_ptr() if n in pd else None for n in names])
+    gtab = (C.c_void_p * len(names))(*[gd[n].data_ptr() if n in gd else None for n in names])
+    td, yd = dev(t), (dev(y) if cond else None)
+    pre_d, emb_d = torch.empty(B, TD, device="cuda"), torch.empty(B, TD, device="cuda")
+    o_d = [torch.empty(B, c, device="cuda") for c in (128, 256, 512)]
+    tdx.check(tdx.lib.tdx_time_mlp_fwd(td.data_ptr(), yd.data_ptr() if cond else None, ptab, pre_d.data_ptr(),
+                                       emb_d.data_ptr(), o_d[0].data_ptr(), o_d[1].data_ptr(), o_d[2].data_ptr(),
+                                       B, stream()))
+    assert rel_err(emb_d, emb.detach()) < 2e-6
+    for got, ref in zip(o_d, outs):
+        assert rel_err(got, ref.detach()) < 2e-6
+    scratch = torch.empty(3 * B * TD, device="cuda")
+    gt_d = [dev(x) for x in gts]
+    tdx.check(tdx.lib.tdx_time_mlp_bwd(td.data_ptr(), yd.data_ptr() if cond else None, ptab, gtab, pre_d.data_ptr(),
+                                       emb_d.data_ptr(), gt_d[0].data_ptr(), gt_d[1].data_ptr(), gt_d[2].data_ptr(),
+                                       scratch.data_ptr(), B, ncls if cond else 0, stream()))
+    for k, v in P.items():
+        assert rel_err(gd[k], v.grad) < 1e-5, k

@@ -413,3 +413,33 @@ def test_sample_chain_T1000_vs_reference_golden(golden_dir):
     drift = rel_mse(x, torch.from_numpy(d["final"]))
     print(f"T=1000 chain, n=4: relative MSE of x_0 vs the reference = {drift:.3e}")
     assert torch.isfinite(x).all() and drift < 1e-8, drift   # measured 7.4e-11
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_eval_step_entry_matches_composed_step(cond):
+    """tdx_unet_eval_step (device step counter + eps_theta + in-place update behind one C-ABI call)
+    is bit-identical to tdx_unet_forward(INFER) + tdx_p_sample_step driven from the host."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+    from tiny_diffusion_amd.schedule import sample_loop
+
+    T, n = 6, 4
+    m = build(cond, 5).eval()
+    g = torch.Generator().manual_seed(77)
+    x_T = torch.randn(n, 1, 28, 28, generator=g)
+    zs = [None] + [torch.randn(n, 1, 28, 28, generator=g) for _ in range(T - 1)]
+    y = torch.randint(0, 10, (n,), generator=g).cuda() if cond else None
+    fp = ForwardProcess(num_timesteps=T)
+    ref = sample_loop(m, fp, "cuda", n, y, x_T=x_T, noises=zs)
+
+    x = x_T.cuda().contiguous()
+    _, _, coef = fp.tables(x.device)
+    counter = torch.tensor([T - 1], dtype=torch.int64, device="cuda")
+    t_idx = torch.empty(1, dtype=torch.int32, device="cuda")
+    t_vec = torch.empty(n, dtype=torch.int64, device="cuda")
+    eps = torch.empty_like(x)
+    junk = torch.full_like(x, 1e6)                     # must be ignored at t == 0
+    for t in reversed(range(T)):
+        z = zs[t].cuda() if t > 0 else junk
+        m._run_eval_step(x, y, coef, counter, t_idx, t_vec, eps, z=z)
+    assert counter.item() == -1 and t_idx.item() == 0
+    assert torch.equal(x, ref)

@@ -114,6 +114,13 @@ _SIGS = {
     "tdx_unet_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     _ptr]),
     "tdx_unet_backward_join": (C.c_int, [_ptr, _ptr]),
+    "tdx_unet_eval_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
+                                     _ptr, C.c_size_t, C.c_int, C.c_uint64, _ptr]),
+    "tdx_time_mlp_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
+    "tdx_time_mlp_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int,
+                                   _ptr]),
+    "tdx_conv3x3_dgrad": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_bn_apply_relu_fwd": (C.c_int, [_ptr, _ptr, C.c_int64, C.c_int, _ptr, _ptr, _ptr]),
     "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
     "tdx_unet_tensor": (C.c_int, [_ptr, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tdx_tune_set": (C.c_int, [C.c_char_p, C.c_int]),

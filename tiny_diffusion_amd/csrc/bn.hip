@@ -144,6 +144,11 @@ int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const flo
   return 0;
 }
 
+extern "C" int tdx_bn_apply_relu_fwd(const float* y, float* out, int64_t rows, int C, const float* scale,
+                                     const float* shift, tdx_stream_t stream) {
+  return tdx_bn_relu_apply(y, out, rows, C, scale, shift, to_stream(stream));
+}
+
 // ------------------------------------------------------------------ backward
 // Rows per block of the reduction pass: sized so that the grid has ~2048 workgroups whatever the
 // layer (the deep layers have few rows but many channels; a fixed 512 rows per block left

@@ -693,6 +693,13 @@ static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
+extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
+                                 int cin, int cout, tdx_stream_t stream) {
+  // the forward kernel on dy with the mirrored, channel-swapped pack: its "cin" is this layer's cout
+  return tdx_conv3x3_fwd(dy, w_dgrad, nullptr, dx, B, H, W, cout, cin, 0, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, stream);
+}
+
 extern "C" int tdx_tune_set(const char* key, int value) {
   if (!key) return TDX_E_BADARG;
   if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }

@@ -101,7 +101,7 @@ __global__ void p_sample_kernel(float4* xo, const float4* x,  // may alias: in-p
     float4 xv = x[i], ev = eps[i], zv = make_float4(0.f, 0.f, 0.f, 0.f), o;
     if (PHILOX) {
       if (t > 0) zv = philox_normal4((uint64_t)i, (uint64_t)t, seed);
-    } else if (z) {
+    } else if (z && t > 0) {  // diffusion.py:267-270: no noise on the last step
       zv = z[i];
     }
     o.x = p_step(xv.x, ev.x, zv.x, c1, c2, sg);

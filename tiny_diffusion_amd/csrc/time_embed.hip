@@ -352,3 +352,23 @@ int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* 
   TDX_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ C ABI (the path on its own)
+extern "C" int tdx_time_mlp_fwd(const int64_t* t, const int64_t* y, const void* const* params, float* pre,
+                                float* emb, float* t1, float* t2, float* t3, int batch, tdx_stream_t stream) {
+  if (!t || !params || !pre || !emb || !t1 || !t2 || !t3 || batch <= 0) return TDX_E_BADARG;
+  return tdx_time_embed_fwd(0, t, y, nullptr, reinterpret_cast<const float* const*>(params), nullptr, pre, emb,
+                            t1, t2, t3, batch, to_stream(stream));
+}
+
+extern "C" int tdx_time_mlp_bwd(const int64_t* t, const int64_t* y, const void* const* params,
+                                void* const* grads, const float* pre, const float* emb, const float* g_t1,
+                                const float* g_t2, const float* g_t3, float* scratch, int batch,
+                                int num_classes, tdx_stream_t stream) {
+  if (!t || !params || !grads || !pre || !emb || !g_t1 || !g_t2 || !g_t3 || !scratch || batch <= 0)
+    return TDX_E_BADARG;
+  if (y && num_classes <= 0) return TDX_E_BADARG;
+  return tdx_time_embed_bwd(0, t, y, reinterpret_cast<const float* const*>(params),
+                            reinterpret_cast<float* const*>(grads), nullptr, pre, emb, g_t1, g_t2, g_t3, scratch,
+                            batch, y ? num_classes : 0, to_stream(stream));
+}

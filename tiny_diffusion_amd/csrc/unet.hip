@@ -768,6 +768,21 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   return 0;
 }
 
+extern "C" int tdx_unet_eval_step(tdx_unet* u, const void* const* params, void* const* buffers, float* x,
+                                  const void* cond, const float* z, const float* coef, int64_t* counter,
+                                  int32_t* t_idx, int64_t* t_vec, float* eps, int64_t n_elems,
+                                  void* workspace, size_t workspace_bytes, int batch, uint64_t philox_seed,
+                                  tdx_stream_t stream) {
+  if (!u || !x || !coef || !counter || !t_idx || !t_vec || !eps || batch <= 0 || n_elems <= 0)
+    return TDX_E_BADARG;
+  RC(tdx_step_begin(counter, t_idx, t_vec, batch, stream));
+  RC(tdx_unet_forward(u, params, buffers, x, t_vec, cond, eps, workspace, workspace_bytes, batch,
+                      TDX_MODE_INFER, stream));
+  // elementwise, so x is updated in place; both kernels skip the noise term at t == 0
+  if (z) return tdx_p_sample_step(x, x, eps, z, coef, t_idx, n_elems, stream);
+  return tdx_p_sample_step_philox(x, x, eps, coef, t_idx, n_elems, philox_seed, stream);
+}
+
 extern "C" int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream) {
   if (!u) return TDX_E_BADARG;
   if (!u->spec || !u->use_streams) return 0;  // everything already ran on the caller's stream

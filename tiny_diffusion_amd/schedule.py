@@ -157,9 +157,20 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
         # advanced by a kernel, so one graph holds several consecutive reverse steps.
         counter = torch.empty(1, dtype=torch.int64, device=device)
 
+        eps_buf = torch.empty_like(x)
+        y_dev = None
+        if y is not None:
+            kind_laion = getattr(getattr(noise_model, "_arch", None), "kind", 0) == 1
+            y_dev = y.contiguous().float() if kind_laion else y.contiguous().to(torch.int64)
+        one_call = hasattr(noise_model, "_run_eval_step")
+
         def steps(k):
             def run():
                 for _ in range(k):
+                    if one_call:  # step counter + eps_theta + update behind one C-ABI entry
+                        noise_model._run_eval_step(x, y_dev, coef, counter, t_idx, t_vec, eps_buf,
+                                                   philox_seed=philox_seed)
+                        continue
                     check(lib.tdx_step_begin(counter.data_ptr(), t_idx.data_ptr(), t_vec.data_ptr(), n_samples, st()),
                           "tdx_step_begin")
                     step_kernels(False)

@@ -339,12 +339,7 @@ class NoiseModelBase(nn.Module):
         out = torch.empty((B,) + tuple(self._arch.in_shape), dtype=torch.float32, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream
         if mode == MODE_INFER:
-            # running statistics are updated by kernels (no torch version bump): _buf_epoch
-            key = tuple(tn._version for tn in ptens if tn is not None) + tuple(tn._version for tn in btens) \
-                + tuple(self._ptab_p.key) + tuple(self._ptab_b.key) + (self._buf_epoch,)
-            if plan.infer_key != key:
-                check(lib.tdx_unet_pack(plan.handle, pptr, bptr, st), "tdx_unet_pack")
-                plan.infer_key = key
+            self._refresh_infer_pack(plan, pptr, ptens, bptr, btens, st)
         else:
             plan.infer_key = None
             plan.generation += 1
@@ -355,6 +350,30 @@ class NoiseModelBase(nn.Module):
                                    plan.workspace.data_ptr(), plan.ws_bytes, B, mode, st),
               "tdx_unet_forward")
         return out, plan, mode
+
+    def _refresh_infer_pack(self, plan, pptr, ptens, bptr, btens, st):
+        """INFER reuses the packed weights / folded BN until a parameter or buffer changes."""
+        # running statistics are updated by kernels (no torch version bump): _buf_epoch
+        key = tuple(tn._version for tn in ptens if tn is not None) + tuple(tn._version for tn in btens) \
+            + tuple(self._ptab_p.key) + tuple(self._ptab_b.key) + (self._buf_epoch,)
+        if plan.infer_key != key:
+            check(lib.tdx_unet_pack(plan.handle, pptr, bptr, st), "tdx_unet_pack")
+            plan.infer_key = key
+
+    def _run_eval_step(self, x, y, coef, counter, t_idx, t_vec, eps, z=None, philox_seed: int = 0):
+        """One reverse step of sample() in place on ``x`` (tdx_unet_eval_step): the step index is
+        read from and decremented in device memory, so the call can sit in a HIP graph."""
+        B = x.shape[0]
+        plan = self._plan(B, x.device)
+        pptr, ptens = self._param_ptrs()
+        bptr, btens = self._buffer_ptrs()
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        self._refresh_infer_pack(plan, pptr, ptens, bptr, btens, st)
+        check(lib.tdx_unet_eval_step(plan.handle, pptr, bptr, x.data_ptr(), None if y is None else y.data_ptr(),
+                                     None if z is None else z.data_ptr(), coef.data_ptr(), counter.data_ptr(),
+                                     t_idx.data_ptr(), t_vec.data_ptr(), eps.data_ptr(), x.numel(),
+                                     plan.workspace.data_ptr(), plan.ws_bytes, B, philox_seed, st),
+              "tdx_unet_eval_step")
 
     def _run_backward(self, plan: _Plan, d_out, grad_views, stage_lo: int = 0, stage_hi: Optional[int] = None):
         pptr, _ = self._param_ptrs()
