@@ -94,8 +94,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every csrc/*.hip for gfx950 and link libtdx.so next to this file."""
     if not force and not is_stale() and not stamp_mismatch():
         return LIB
-    hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
+    # one builder at a time: under torch.distributed.run every rank imports the package at once
+    import fcntl
+
+    with open(os.path.join(OBJDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale() and not stamp_mismatch():
+            return LIB  # another process finished the build while this one waited
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
+    hipcc = _hipcc()
     hdr_t = _deps_mtime()
     if not _stamp_matches():
         force = True  # objects were built with other flags
