@@ -50,6 +50,18 @@ def test_param_slots_and_stage_buckets_cover_all_parameters():
     staged = [n for st in backward_stage_params(True) for n in st]
     assert sorted(staged) == sorted(names) and len(backward_stage_params(True)) == 15
     assert param_slot_names(False)[4] is None
+    # flat-buffer layout: every bucket of the gradient all-reduce is ONE contiguous slice
+    from tiny_diffusion_amd.train import plan_buckets
+
+    params = dict(m.named_parameters())
+    assert sorted(m._param_order) == sorted(names)
+    offsets, o = {}, 0
+    for n in m._param_order:
+        offsets[n] = (o, o + params[n].numel())
+        o += params[n].numel()
+    buckets = plan_buckets(offsets, True, 1 << 20)
+    assert all(len(ranges) == 1 for _, ranges in buckets), buckets
+    assert sum(hi - lo for _, r in buckets for lo, hi in r) == o
 
 
 def test_cpu_tensors_fail_loudly():

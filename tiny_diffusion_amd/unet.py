@@ -210,7 +210,12 @@ class NoiseModelBase(nn.Module):
         cond = self.num_classes > 0
         self._slot_names = param_slot_names(cond, arch.time_name, arch.init_name, arch.final_name)
         self._buf_names = buffer_slot_names()
-        self._param_order = [n for n in self._slot_names if n is not None]
+        # layout of the flat parameter / gradient buffers: the parameters of the LAST backward stage
+        # (time path, class embedding, first layer) sit together so that the final, exposed bucket
+        # of the gradient all-reduce is one contiguous slice = one collective
+        names = [n for n in self._slot_names if n is not None]
+        self._param_order = ([n for n in names if n.startswith("time_proj")]
+                             + [n for n in names if not n.startswith("time_proj")])
         self._plans = {}
         self._ptab_p, self._ptab_b, self._ptab_g = _PtrTable(), _PtrTable(), _PtrTable()
         self._grad_flat = None
