@@ -443,3 +443,22 @@ def test_eval_step_entry_matches_composed_step(cond):
         m._run_eval_step(x, y, coef, counter, t_idx, t_vec, eps, z=z)
     assert counter.item() == -1 and t_idx.item() == 0
     assert torch.equal(x, ref)
+
+
+def test_empty_batch_behaviour():
+    """Eval mode passes an empty batch through (as torch's layers do); train mode refuses it;
+    sample(n_samples=0) returns an empty tensor."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess, sample
+
+    m = build(False, 3)
+    x = torch.empty(0, 1, 28, 28, device="cuda")
+    t = torch.empty(0, dtype=torch.int64, device="cuda")
+    m.eval()
+    assert m(x, t).shape == (0, 1, 28, 28)
+    with torch.no_grad():
+        assert m(x, t).shape == (0, 1, 28, 28)
+    m.train()
+    with pytest.raises(ValueError):
+        m(x, t)
+    out = sample(m, ForwardProcess(num_timesteps=3), "cuda", n_samples=0)
+    assert out.shape == (0, 1, 28, 28) and m.training is False

@@ -119,6 +119,8 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
     x = (torch.randn(n_samples, *shape) if x_T is None else x_T).to(device).float().contiguous()
     if y is not None:
         y = y.to(device)
+    if n_samples == 0:
+        return x  # nothing to denoise (the reference loops over empty tensors)
     T = diffusion.num_timesteps
     _, _, coef = diffusion.tables(device)
     t_idx = torch.empty(1, dtype=torch.int32, device=device)

@@ -333,6 +333,12 @@ class NoiseModelBase(nn.Module):
     def _run_forward(self, x, t, y, mode: Optional[int] = None):
         self._check_inputs(x, t, y)
         B = x.shape[0]
+        if B == 0:
+            # torch's layers pass an empty batch through in eval mode; train-mode BatchNorm has no
+            # statistics to compute (torch yields NaN running buffers there: refused instead)
+            if (self._mode() if mode is None else mode) == MODE_TRAIN:
+                raise ValueError("empty batch in train mode: BatchNorm statistics are undefined")
+            return x.new_empty((0,) + tuple(self._arch.in_shape), dtype=torch.float32), None, MODE_INFER
         plan = self._plan(B, x.device)
         mode = self._mode() if mode is None else mode
         pptr, ptens = self._param_ptrs()
@@ -394,7 +400,7 @@ class NoiseModelBase(nn.Module):
     # ------------------------------------------------------------------ forward
     def _forward_impl(self, x, t, y):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if not needs_grad:
+        if not needs_grad or (x.shape[0] == 0 and not self.training):
             return self._run_forward(x, t, y)[0]
         d = dict(self.named_parameters())
         params = [d[n] for n in self._param_order]
