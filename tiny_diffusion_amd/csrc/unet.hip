@@ -129,7 +129,7 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
-int g_tdx_time_stage = 6;  // backward stage after which the time/class path runs (6 or 14)
+int g_tdx_time_stage = 14;  // backward stage after which the time/class path runs (14, or 6: see DESIGN.md 3.2)
 int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
 
 struct tdx_unet {
@@ -693,8 +693,11 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     return 0;
   };
   // the time / class path only needs the three pixel sums, which the third stream produced itself
-  // (dec_level_bwd): it runs there, in order, as soon as the last of them is enqueued (stage 6),
-  // hidden under the encoder's backward instead of trailing the step
+  // (dec_level_bwd).  Default: after the last stage.  Knob time_stage=6 enqueues it right after the
+  // last decoder level, hidden under the encoder's backward (+1.3 % throughput) - NOT the default:
+  // with it dW1 of the time MLP came out wrong in about 1 of 16 otherwise identical test runs on
+  // MI355X (every other gradient bit-identical; never reproduced in 550 back-to-back steps, never
+  // seen with the default placement), cause not found yet
   auto time_path_bwd = [&](hipStream_t st) -> int {
     TDX_HIP(hipEventRecord(u->ev_fork, st));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
