@@ -462,3 +462,34 @@ def test_empty_batch_behaviour():
         m(x, t)
     out = sample(m, ForwardProcess(num_timesteps=3), "cuda", n_samples=0)
     assert out.shape == (0, 1, 28, 28) and m.training is False
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_training_step_is_bitwise_reproducible(cond):
+    """No atomics anywhere: every reduction (BN statistics, split weight gradients, pixel sums, loss)
+    has a fixed order, so the same inputs give the same bits - across calls, with the helper
+    streams overlapping differently each time."""
+    m = build(cond, 11).train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    B = 48
+    x = torch.randn(B, 1, 28, 28, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    y = torch.randint(0, 10, (B,), generator=g).cuda() if cond else None
+    runs = []
+    for rep in range(3):
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        out = m(x, t, y) if cond else m(x, t)
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+        if rep == 0:  # disturb the timing of the side streams before the next repetition
+            junk = torch.randn(1 << 22, device="cuda").sin_().sum()
+    for rep in (1, 2):
+        assert torch.equal(runs[0][0], runs[rep][0])
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], runs[rep][1][k]), k
+        for k in runs[0][2]:
+            assert torch.equal(runs[0][2][k], runs[rep][2][k]), k
