@@ -335,7 +335,7 @@ int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream);
  * conditional_diffusion.py:31, 121-125): emb = W2 silu(W1 float(t) + b1) + b2 [+ E[y]], then the
  * three 1x1 projections.  params/grads: TDX_P_COUNT tables (only the TE, CLASS_EMB, TP slots are read /
  * written).  pre, emb (B,256); t1 (B,128), t2 (B,256), t3 (B,512); y NULL = unconditional.
- * bwd: g_t1..3 are d(loss)/d(t1..3) (already summed over pixels); scratch 3*B*256 floats. */
+ * bwd: g_t1..3 are d(loss)/d(t1..3) (already summed over pixels); scratch (3*256 + 1)*B floats. */
 int tdx_time_mlp_fwd(const int64_t* t, const int64_t* y, const void* const* params, float* pre,
                      float* emb, float* t1, float* t2, float* t3, int batch, tdx_stream_t stream);
 int tdx_time_mlp_bwd(const int64_t* t, const int64_t* y, const void* const* params,

@@ -489,7 +489,7 @@ def test_time_mlp_fwd_bwd(tdx, cond):
     assert rel_err(emb_d, emb.detach()) < 2e-6
     for got, ref in zip(o_d, outs):
         assert rel_err(got, ref.detach()) < 2e-6
-    scratch = torch.empty(3 * B * TD, device="cuda")
+    scratch = torch.empty((3 * TD + 1) * B, device="cuda")
     gt_d = [dev(x) for x in gts]
     tdx.check(tdx.lib.tdx_time_mlp_bwd(td.data_ptr(), yd.data_ptr() if cond else None, ptab, gtab, pre_d.data_ptr(),
                                        emb_d.data_ptr(), gt_d[0].data_ptr(), gt_d[1].data_ptr(), gt_d[2].data_ptr(),

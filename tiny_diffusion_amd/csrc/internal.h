@@ -41,11 +41,12 @@ int tdx_pack_conv3x3_pad(const float* w_oihw, float* w_fwd, float* w_dgrad, int 
                          int cin, tdx_stream_t stream);
 int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int splits, int cout, int cin,
                                  int cin_real, tdx_stream_t stream);
-int tdx_time_embed_bwd_ex(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+// tf: float(t) per sample, as stored by the forward (tdx_time_embed_fwd kind 0 -> sin, tdx_time_embed_only)
+int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st);
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
-                        int B, hipStream_t st);
+                        float* tf_out, int B, hipStream_t st);
 // latent MLP noise model (latent_diffusion.py:16-128), kind TDX_UNET_LATENT_MLP of tdx_unet_*
 size_t tdx_latent_workspace_floats(int B);
 size_t tdx_latent_infer_ss_floats(void);

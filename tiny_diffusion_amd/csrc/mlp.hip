@@ -468,7 +468,7 @@ const int TPW[3] = {64, 128, 256};  // time_proj widths
 inline size_t al64(size_t n) { return (n + 63) / 64 * 64; }
 
 struct LLayout {
-  size_t z, t, y, pre, emb, tp[3], x0, Y[13], ss[13], cat[3], a[13];  // a[u]: dense post-activation (where used)
+  size_t z, t, tf, y, pre, emb, tp[3], x0, Y[13], ss[13], cat[3], a[13];  // a[u]: dense post-activation (where used)
   size_t gA[13], gY, gcat[3], gx0, timescr, total;
 };
 
@@ -477,7 +477,7 @@ LLayout latent_layout(int B) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += al64(n); return r; };
   const size_t b = (size_t)B;
-  L.z = take(b * LATENT); L.t = take(2 * b); L.y = take(2 * b);
+  L.z = take(b * LATENT); L.t = take(2 * b); L.tf = take(b); L.y = take(2 * b);
   L.pre = take(b * TDM); L.emb = take(b * TDM);
   for (int k = 0; k < 3; ++k) L.tp[k] = take(b * TPW[k]);
   L.x0 = take(b * 512);
@@ -563,7 +563,7 @@ int tdx_latent_forward(const float* const* P, void* const* buffers, const float*
     TDX_HIP(hipMemcpyAsync(ws + L.t, t, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     TDX_HIP(hipMemcpyAsync(ws + L.y, y, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
   }
-  RC(tdx_time_embed_only(t, y, P, ws + L.pre, ws + L.emb, B, st));
+  RC(tdx_time_embed_only(t, y, P, ws + L.pre, ws + L.emb, ws + L.tf, B, st));
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k)
     RC(linear_fwd(ws + L.emb, TDM, P[pw[k]], P[pw[k] + 1], ws + L.tp[k], TPW[k], B, TPW[k], TDM, 0, nullptr,
@@ -639,7 +639,7 @@ int tdx_latent_backward(const float* const* P, float* const* G, const float* d_o
       RC(colsum(ws + L.gx0, 512, B, 512, G[TDX_P_INIT_B], st));
       const float* gt[3] = {ws + L.gcat[0], ws + L.gcat[1], ws + L.gcat[2]};
       const int ldg[3] = {128, 256, 512};
-      RC(tdx_time_embed_bwd_ex(reinterpret_cast<const int64_t*>(ws + L.t), reinterpret_cast<const int64_t*>(ws + L.y),
+      RC(tdx_time_embed_bwd_ex(ws + L.tf, reinterpret_cast<const int64_t*>(ws + L.y),
                                P, G, ws + L.pre, ws + L.emb, gt, ldg, TPW, ws + L.timescr, B, ncls, st));
     }
   }

@@ -39,10 +39,11 @@ time_emb_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ y,
                 const float* __restrict__ w1, const float* __restrict__ b1,
                 const float* __restrict__ w2, const float* __restrict__ b2,
                 const float* __restrict__ cls, float* __restrict__ pre_out,
-                float* __restrict__ emb_out) {
+                float* __restrict__ emb_out, float* __restrict__ tf_out) {
   __shared__ __attribute__((aligned(16))) float h[TD];
   const int n = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float tf = (float)t[n];
+  if (tf_out && q == 0 && tid == 0) tf_out[n] = tf;  // float(t) kept for the backward (dW1 = sum g_pre * t)
   const float pre = fmaf(w1[tid], tf, b1[tid]);  // Linear(1, 256): weight (256,1)
   if (pre_out && q == 0) pre_out[(size_t)n * TD + tid] = pre;
   h[tid] = silu_f(pre);
@@ -180,7 +181,7 @@ int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float
                        float* t3, int B, hipStream_t st) {
   if (kind == 1) return time_embed_fwd_laion(t, cond, P, sin, pre, emb, t1, t2, t3, B, st);
   time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
-                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb);
+                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb, sin);
   TDX_CHECK_LAUNCH();
   time_proj_kernel<<<dim3(B, 14), 256, 0, st>>>(emb, P[TDX_P_TP1_W], P[TDX_P_TP1_B], P[TDX_P_TP2_W],
                                                 P[TDX_P_TP2_B], P[TDX_P_TP3_W], P[TDX_P_TP3_B], t1,
@@ -221,10 +222,11 @@ __global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __res
 }
 
 // g_pre = g_h * silu'(pre);  dW1[j] = sum_n g_pre[n][j] * t[n];  db1[j] = sum_n g_pre[n][j]
+// tf = float(t) as the forward computed and stored it (no int64 -> float sequence in the loop)
 // block = 32 columns j x 8 interleaved slices of n
 __global__ void __launch_bounds__(256)
 time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
-                   const int64_t* __restrict__ t, float* __restrict__ dw1, float* __restrict__ db1,
+                   const float* __restrict__ tf, float* __restrict__ dw1, float* __restrict__ db1,
                    int B) {
   __shared__ float red[2][8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -233,7 +235,7 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
 #pragma unroll 4
   for (int n = sl; n < B; n += 8) {
     const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
-    sw = fmaf(gp, (float)t[n], sw);
+    sw = fmaf(gp, tf[n], sw);
     sb += gp;
   }
   red[0][sl][cl] = sw;
@@ -304,7 +306,7 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
 
 // kind-0 time path backward with the three projection gradients given as strided views
 // (g_tk[n*ldg[k] + o], o < widths[k]).  scratch: g_emb (B*256) | h (B*256) | g_h (B*256)
-int tdx_time_embed_bwd_ex(const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
+int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st) {
   float* g_emb = scratch;
@@ -329,7 +331,7 @@ int tdx_time_embed_bwd_ex(const int64_t* t, const int64_t* y, const float* const
   TDX_CHECK_LAUNCH();
   lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0, TD);
   TDX_CHECK_LAUNCH();
-  time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -341,16 +343,22 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
   if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int widths[3] = {128, 256, 512};
-  return tdx_time_embed_bwd_ex(t, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st);
+  (void)t;
+  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st);
 }
 
 // emb only (kind-0 formula): the latent model applies its own projection widths
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
-                        int B, hipStream_t st) {
+                        float* tf_out, int B, hipStream_t st) {
   time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
-                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb);
+                                              P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb, tf_out);
   TDX_CHECK_LAUNCH();
   return 0;
+}
+
+__global__ void t_to_float_kernel(const int64_t* __restrict__ t, float* __restrict__ tf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tf[i] = (float)t[i];
 }
 
 // ------------------------------------------------------------------ C ABI (the path on its own)
@@ -368,7 +376,11 @@ extern "C" int tdx_time_mlp_bwd(const int64_t* t, const int64_t* y, const void* 
   if (!t || !params || !grads || !pre || !emb || !g_t1 || !g_t2 || !g_t3 || !scratch || batch <= 0)
     return TDX_E_BADARG;
   if (y && num_classes <= 0) return TDX_E_BADARG;
+  // float(t) behind the three B x 256 scratch blocks (the network keeps it from its forward)
+  float* tf = scratch + (size_t)3 * batch * TD;
+  t_to_float_kernel<<<cdiv(batch, 256), 256, 0, to_stream(stream)>>>(t, tf, batch);
+  TDX_CHECK_LAUNCH();
   return tdx_time_embed_bwd(0, t, y, reinterpret_cast<const float* const*>(params),
-                            reinterpret_cast<float* const*>(grads), nullptr, pre, emb, g_t1, g_t2, g_t3, scratch,
+                            reinterpret_cast<float* const*>(grads), tf, pre, emb, g_t1, g_t2, g_t3, scratch,
                             batch, y ? num_classes : 0, to_stream(stream));
 }

@@ -694,10 +694,12 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   };
   // the time / class path only needs the three pixel sums, which the third stream produced itself
   // (dec_level_bwd).  Default: after the last stage.  Knob time_stage=6 enqueues it right after the
-  // last decoder level, hidden under the encoder's backward (+1.3 % throughput) - NOT the default:
-  // with it dW1 of the time MLP came out wrong in about 1 of 16 otherwise identical test runs on
-  // MI355X (every other gradient bit-identical; never reproduced in 550 back-to-back steps, never
-  // seen with the default placement), cause not found yet
+  // last decoder level, hidden under the encoder's backward (+0.8..1.3 % throughput).  Opt-in only:
+  // with the first version of time_l1_bwd_kernel (int64 t converted in the loop) that placement
+  // produced a wrong dW1 in some workgroups when the kernel ran beside the weight-gradient GEMMs
+  // (memory was right - a snapshot kernel on the same stream just before read t correctly - and any
+  // change to the kernel's code made it disappear).  The kernel now reads float(t)
+  // stored by the forward and tools/gpu_time_stage6_check.py passes, but the default stays put.
   auto time_path_bwd = [&](hipStream_t st) -> int {
     TDX_HIP(hipEventRecord(u->ev_fork, st));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
