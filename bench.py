@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark of the tiny-diffusion DDPM hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full training step of the unconditional MNIST 28x28 UNet in fp32 on a
@@ -31,6 +31,8 @@ PER_GPU_BATCH = 256
 FWD_FLOP_PER_IMAGE = 2_250_805_760          # SURVEY.md 8(d), measured on the reference
 TRAIN_FLOP_PER_IMAGE = 3 * FWD_FLOP_PER_IMAGE
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md (dense fp32 matrix)
+PEAK_HBM_TBPS = 8.0                         # MI355X_MICROARCH.md (HBM3E spec; ~6.3 achievable)
+PROFILE_TAG = "r02"                         # profiles/<tag>_* hold the rocprofv3 evidence of this round
 
 # (cin, cout, H) of the 13 conv/BN units, diffusion.py:32-95
 # (cin, cout, hw, in_bn): in_bn = the unit reads the previous unit's pre-BN tensor and applies
@@ -104,12 +106,16 @@ def conv_roofline(B: int, reps: int = 5):
 def pmc_traffic():
     """HBM bytes per conv launch from the committed PMC passes over this same leg (bench.py cannot
     collect counters itself): tools/pmc_traffic.py -> profiles/r01_end_pmc_hbm_traffic.json."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_end_pmc_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    for tag in (PROFILE_TAG, "r01_end"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["source"] = f"profiles/{tag}_pmc_hbm_traffic.json"
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def roofline_block(B: int):
@@ -126,7 +132,8 @@ def roofline_block(B: int):
         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
         "traffic": None if pmc is None else round(pmc["traffic_mb_per_launch"] * 1e6),
         "traffic_note": "HBM bytes per launch, rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, separate passes over this leg "
-                        "(profiles/r01_end_pmc_hbm_traffic.*); algorithmic minimum in algorithmic_bytes_per_launch",
+                        f"({'none' if pmc is None else pmc['source']}); algorithmic minimum in "
+                        "algorithmic_bytes_per_launch",
         "algorithmic_bytes_per_launch": round(alg / nl),
         "kernel": "conv3x3_igemm_dma_kernel / conv3x3_igemm_kernel (fwd, dgrad) + "
                   "conv3x3_wgrad_dma_kernel / conv3x3_wgrad_kernel + wgrad split reduce excluded",
@@ -136,13 +143,27 @@ def roofline_block(B: int):
     }
 
 
-def cpu_baseline(batch: int = 64, steps: int = 6, threads: int = 16):
-    """The CPU oracle (port of diffusion.py:214-236: q_sample + fwd + MSE + bwd + Adam) on this
-    host's cores; bounded sample, reported beside the GPU number, never the target."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch: int = 64, steps: int = 10, warm: int = 2, sample_steps: int = 20):
+    """the CPU oracle (port of diffusion.py:214-236 and 254-276, checked against
+    the reference's own outputs) on ALL host cores of this box, configs[0] (unconditional, B = 64,
+    fp32): 2 warm-up + 10 timed train steps (q_sample + fwd + MSE + bwd + Adam) and 2 + 20 timed
+    reverse steps (eval forward + p_sample), the latter extrapolated x1000/20 to a chain.  A bounded
+    sample, reported beside the GPU number, never the target."""
     from oracle import ref_cpu as R
     from oracle.weights import make_state_dict
 
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    threads = max(1, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     sd = make_state_dict(0, False)
     sched = R.Schedule()
@@ -151,7 +172,7 @@ def cpu_baseline(batch: int = 64, steps: int = 6, threads: int = 16):
     state = {}
     params = {k: v.clone() for k, v in sd.items() if "running" not in k and "num_batches" not in k}
     times = []
-    for i in range(steps + 1):
+    for i in range(warm + steps):
         t0 = time.perf_counter()
         t = torch.randint(0, 1000, (batch,), generator=g)
         noise = torch.randn(x0.shape, generator=g)
@@ -161,9 +182,177 @@ def cpu_baseline(batch: int = 64, steps: int = 6, threads: int = 16):
         R.adam_step(params, grads, state)
         sd.update(bufs)
         times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / steps          # first step is warm-up
+    dt = sum(times[warm:]) / steps
+    # reverse steps (diffusion.py:259-274) at n = 64, eval-mode forward
+    full = dict(sd); full.update(params)
+    p, b = R.split_state(full)
+    x = torch.randn(batch, 1, 28, 28, generator=g)
+    stimes = []
+    with torch.no_grad():
+        for i in range(warm + sample_steps):
+            t0 = time.perf_counter()
+            tt = 999 - i
+            eps = R.unet_forward(p, b, x, torch.full((batch,), tt, dtype=torch.long), training=False)
+            x = R.p_sample_step(sched, x, eps, tt, torch.randn(x.shape, generator=g))
+            stimes.append(time.perf_counter() - t0)
+    sdt = sum(stimes[warm:]) / sample_steps
     return {"value": round(batch / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} train steps at B={batch} (configs[0]) after 1 warm-up, oracle/ref_cpu.py"}
+            "cpu_model": _cpu_model(),
+            "sample": f"{steps} train steps at B={batch} (configs[0]) after {warm} warm-up, oracle/ref_cpu.py; "
+                      f"{sample_steps} reverse steps at n={batch} after {warm} warm-up",
+            "train_ms_per_step": round(dt * 1e3, 1),
+            "sample_step_ms_n64": round(sdt * 1e3, 1),
+            "sample_chain_s_n64_extrapolated": round(sdt * 1000, 1)}
+
+
+def _time_ms(fn, reps: int, warm: int = 2):
+    """Average duration of fn() over `reps` back-to-back calls, HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def peak_probes():
+    """Measured denominators ('ship a peak_probe and divide by the MEASURED peak,
+    reporting both'): tdx_probe_mfma_f32 = back-to-back v_mfma_f32_32x32x2_f32 on four independent
+    accumulators per wave, one wave per SIMD on every CU; tdx_probe_stream_copy = float4 copy of
+    1 GiB (read + write counted)."""
+    from tiny_diffusion_amd._lib import lib, check
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    blocks, iters = 256 * 4, 4096
+    out = torch.empty(blocks * 256, device=dev)
+    ms = _time_ms(lambda: check(lib.tdx_probe_mfma_f32(out.data_ptr(), iters, blocks, st)), 5)
+    flop = blocks * 4 * iters * 4 * (2.0 * 32 * 32 * 2)     # blocks x waves x iters x chains x FLOP/MFMA
+    n = 1 << 28                                              # 1 GiB of floats
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    a.normal_()
+    cms = _time_ms(lambda: check(lib.tdx_probe_stream_copy(a.data_ptr(), b.data_ptr(), n, st)), 5)
+    return {"mfma_f32_tflops": round(flop / ms / 1e9, 1), "hbm_copy_tbps": round(2 * 4.0 * n / cms / 1e9, 2)}
+
+
+def hbm_kernels(B: int, copy_tbps: float):
+    """GB/s of the HBM-bound kernels of the step: algorithmic bytes / HIP-event time,
+    against the 8 TB/s spec and against the measured copy rate."""
+    from tiny_diffusion_amd._lib import lib, check
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    fp = ForwardProcess()
+    rows = {}
+
+    def add(name, nbytes, ms, note):
+        tb = nbytes / ms / 1e9
+        rows[name] = {"gbps": round(tb * 1e3, 1), "us": round(ms * 1e3, 2), "bytes": int(nbytes),
+                      "frac_of_8tbps": round(tb / PEAK_HBM_TBPS, 3),
+                      "frac_of_measured_copy": round(tb / copy_tbps, 3) if copy_tbps else None, "what": note}
+
+    # the elementwise kernels at the benchmark's own size are 0.8 MB launches (latency, not bandwidth):
+    # they are timed at 64x the batch as well so that the kernel, not the launch, is what is measured
+    for tag, nb in (("", B), ("_x64", 64 * B)):
+        x0 = torch.rand(nb, 1, 28, 28, device=dev)
+        t = torch.randint(0, 1000, (nb,), device=dev)
+        ms = _time_ms(lambda: fp.q_sample_philox(x0, t, 1, 0), 20)
+        add("q_sample_philox" + tag, 12.0 * x0.numel(), ms, f"read x0, write x_t + eps, in-kernel Philox; B={nb}")
+        eps = torch.randn_like(x0)
+        sa, sb, coef = fp.tables(dev)
+        ti = torch.tensor([500], dtype=torch.int32, device=dev)
+        ms = _time_ms(lambda: check(lib.tdx_p_sample_step_philox(x0.data_ptr(), x0.data_ptr(), eps.data_ptr(),
+                                                                 coef.data_ptr(), ti.data_ptr(), x0.numel(), 7, st)), 20)
+        add("p_sample_philox" + tag, 12.0 * x0.numel(), ms, f"read x, eps; write x; in-kernel noise; n={nb}")
+    # BatchNorm+ReLU backward of the largest unit (dec1.0 output: 256x32x32x64) and a deep one
+    for cout, H in ((64, 32), (128, 28), (512, 7)):
+        M = B * H * H
+        g = torch.randn(M * cout, device=dev)
+        y = torch.randn(M * cout, device=dev)
+        ss = torch.rand(4 * cout, device=dev) + 0.5
+        gamma = torch.ones(cout, device=dev)
+        dg, db, dbias = (torch.empty(cout, device=dev) for _ in range(3))
+        scr = torch.empty(lib.tdx_bn_relu_bwd_scratch_floats(M, cout), device=dev)
+        ms = _time_ms(lambda: check(lib.tdx_bn_relu_bwd(g.data_ptr(), y.data_ptr(), M, cout, ss.data_ptr(),
+                                                        ss[cout:].data_ptr(), ss[2 * cout:].data_ptr(),
+                                                        ss[3 * cout:].data_ptr(), gamma.data_ptr(), dg.data_ptr(),
+                                                        db.data_ptr(), dbias.data_ptr(), scr.data_ptr(), 1, st)), 10)
+        add(f"bn_relu_bwd_c{cout}_hw{H}", 20.0 * M * cout, ms, "read g, y twice; write g (reduce + finalize + apply)")
+    n = 11_182_273
+    pa, gr, m1, m2 = (torch.randn(n, device=dev) * 0.01 for _ in range(4))
+    m2.abs_()
+    ms = _time_ms(lambda: check(lib.tdx_adam_step(pa.data_ptr(), gr.data_ptr(), m1.data_ptr(), m2.data_ptr(), n,
+                                                  1e-3, 0.9, 0.999, 1e-8, 3, 1.0, st)), 20)
+    add("adam", 28.0 * n, ms, "read p, g, m, v; write p, m, v; 11.18 M parameters")
+    return rows
+
+
+def in_situ():
+    """Sum of the MFMA convolution kernel durations INSIDE the real training step (three streams,
+    kernels sharing CUs), from the committed rocprofv3 kernel trace of the training leg
+    (tools/insitu.py -> profiles/<tag>_insitu.json): the isolated-launch roofline above is an upper
+    bound on what the step sees."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_insitu.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def first_step_parity(model, fp, x0, seed: int):
+    """Outside the timed region: eps_hat of the benchmark's own first forward (train-mode BatchNorm,
+    B = 256, in-kernel Philox noise) against the CPU oracle on the same x_t, t and weights
+    (diffusion.py:225-228); the BatchNorm buffers are put back afterwards."""
+    from oracle import ref_cpu as R
+    from tiny_diffusion_amd.unet import MODE_TRAIN
+
+    dev = x0.device
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator(device=dev).manual_seed(4242)
+    t = torch.randint(0, fp.num_timesteps, (x0.shape[0],), device=dev, generator=g)
+    x_t, noise = fp.q_sample_philox(x0, t, seed, 0)
+    eps, _, _ = model._run_forward(x_t, t, None, mode=MODE_TRAIN)
+    torch.cuda.synchronize()
+    p, b = R.split_state(sd)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = R.unet_forward(p, b, x_t.cpu(), t.cpu(), training=True)
+    d = eps.cpu().double() - ref.double()
+    mse = (d ** 2).mean().item()
+    rel = mse / max((ref.double() ** 2).mean().item(), 1e-30)
+    with torch.no_grad():
+        for k, v in model.named_buffers():
+            v.copy_(sd[k])
+    model._buf_epoch += 1
+    if not (mse < 1e-5 and rel < 1e-9):
+        raise SystemExit(f"bench: eps_hat of the first step disagrees with the CPU oracle: MSE {mse:.3e}, "
+                         f"relative {rel:.3e}")
+    return {"batch": int(x0.shape[0]), "eps_mse_vs_oracle": float(f"{mse:.3e}"),
+            "eps_rel_mse_vs_oracle": float(f"{rel:.3e}"), "gate": "MSE < 1e-5 (north_star) and relative MSE < 1e-9"}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script through
+    torch.distributed.run (one process per GPU, RCCL) from a parent that has not touched the GPU,
+    pass their output through and exit with their status."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def sample_latency(model, diffusion, n: int):
@@ -275,6 +464,17 @@ def latent_extras(steps: int = 200, warmup: int = 20):
     return out
 
 
+def timed_steps(ts, x0, warmup: int, steps: int, barrier):
+    for _ in range(warmup):
+        ts.step(x0)
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step(x0)
+    torch.cuda.synchronize(); barrier()
+    return time.perf_counter() - t0, loss
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +483,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu baseline / sampling legs")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-launch conv timing leg (for rocprofv3 cross-checks)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="run only the timed training steps (for rocprofv3 traces of the real step)")
     args = ap.parse_args()
     if args.roofline_only:
         torch.cuda.set_device(0)
@@ -292,9 +494,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet)
+        sys.exit(self_launch(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU; (a rehearsal with more ranks than GPUs - gloo only - wraps around)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -315,7 +519,7 @@ def main():
     torch.manual_seed(0)                      # identical init on every rank
     model = NoiseModel().to(dev).train()
     fp = ForwardProcess()
-    ts = TrainStep(model, fp, lr=1e-3, philox_seed=1234 + rank)
+    ts = TrainStep(model, fp, lr=1e-3, philox_seed=1234)   # the Philox stream is keyed by (step, rank)
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev).manual_seed(rank)
     x0 = torch.rand(PER_GPU_BATCH, 1, 28, 28, device=dev, generator=g) * 2 - 1   # Normalize(0.5,0.5) range
@@ -324,14 +528,10 @@ def main():
         if use_dist:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        ts.step(x0)
-    torch.cuda.synchronize(); barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = ts.step(x0)
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
+    parity = None
+    if rank == 0 and not args.train_only:
+        parity = first_step_parity(model, fp, x0, 1234)   # untimed; the other ranks wait at the barrier
+    dt, loss = timed_steps(ts, x0, args.warmup, args.steps, barrier)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -339,6 +539,7 @@ def main():
     loss_v = loss.item()
     if not (loss_v == loss_v) or loss_v > 1e3:
         raise SystemExit(f"training diverged in the benchmark: loss {loss_v}")
+    single = None
     if world > 1:
         # outside the timed region: replicas must still hold identical parameters
         probe = torch.stack([ts.flat_param.double().sum(), ts.flat_param.double().pow(2).sum()])
@@ -347,6 +548,17 @@ def main():
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise SystemExit(f"data-parallel replicas diverged: {lo.tolist()} vs {hi.tolist()}")
+        # the same step with the gradient exchange switched off, on every GPU at once: what one rank
+        # does alone on this node right now (context for the driver's own scaling computation)
+        torch.manual_seed(0)
+        m1 = NoiseModel().to(dev).train()
+        ts1 = TrainStep(m1, fp, lr=1e-3, philox_seed=1234, data_parallel=False)
+        k1 = max(2, min(args.steps, 20))
+        dt1, _ = timed_steps(ts1, x0, min(args.warmup, 5), k1, barrier)
+        r1 = torch.tensor([PER_GPU_BATCH * k1 / dt1], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(r1)
+        single = r1.item() / world
+        del ts1, m1
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -364,11 +576,24 @@ def main():
             "images_per_s_per_gpu": round(value / world, 1),
             "loss_after": round(loss_v, 5),
             "train_tflops_per_gpu": round(value / world * TRAIN_FLOP_PER_IMAGE / 1e12, 2),
+            "parity_check": parity,
         }
-        if not args.no_extras and world == 1:
+        if single is not None:
+            res["weak_scaling"] = {
+                "single_rank_images_per_s": round(single, 1),
+                "efficiency": round(value / world / single, 4),
+                "note": "single_rank = the same step with the gradient all-reduce disabled, timed on all "
+                        f"{world} GPUs at once after the main region (mean over ranks); backend " + backend}
+        if not args.no_extras and not args.train_only and world == 1:
+            probes = peak_probes()
             res["roofline"] = roofline_block(PER_GPU_BATCH)
+            res["roofline"]["peak_measured"] = probes["mfma_f32_tflops"]
+            res["roofline"]["frac_of_measured_peak"] = round(res["roofline"]["achieved"] / probes["mfma_f32_tflops"], 4)
             res["roofline"]["whole_step_frac"] = round(
                 value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            res["roofline"]["in_situ"] = in_situ()
+            res["hbm_bound_kernels"] = {"peak_tbps": PEAK_HBM_TBPS, "peak_measured_copy_tbps": probes["hbm_copy_tbps"],
+                                        "kernels": hbm_kernels(PER_GPU_BATCH, probes["hbm_copy_tbps"])}
             res["cpu_baseline"] = cpu_baseline()
             model.eval()
             s16, s64 = sample_latency(model, fp, 16), sample_latency(model, fp, 64)
@@ -376,10 +601,11 @@ def main():
             res["sample"] = {"unit": "s per 1000-step chain (HIP-graph replay, in-kernel Philox noise)",
                              "n16": round(s16, 3), "n64": round(s64, 3),
                              "n16_tflops": round(16 * 1000 * fwd / s16 / 1e12, 1),
-                             "n64_tflops": round(64 * 1000 * fwd / s64 / 1e12, 1)}
+                             "n64_tflops": round(64 * 1000 * fwd / s64 / 1e12, 1),
+                             "cpu_n64_extrapolated_s": res["cpu_baseline"]["sample_chain_s_n64_extrapolated"]}
             res["laion_unet"] = laion_extras()
             res["latent_mlp"] = latent_extras()
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TDX_VERSION 100 /* 0.1.0 */
+#define TDX_VERSION 200 /* 0.2.0: tdx_time_mlp_bwd scratch (3*256+1)*B floats; new exports */
 
 #define TDX_E_BADARG (-1)   /* null pointer, size <= 0, batch > plan capacity ... */
 #define TDX_E_SHAPE (-2)    /* shape the kernel family does not cover */
@@ -144,6 +144,15 @@ int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias,
 size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout);
+/* 1 when (B,H,W,cin,cout) is addressable by the convolution kernels: they use 32-bit buffer
+ * offsets with 0x80000000 as the zero-padding sentinel, so every activation tensor of the layer
+ * (plus (W+1) pixels of slack on both sides) must stay below 2 GiB; the entry points return
+ * TDX_E_SHAPE otherwise (MNIST UNet: per-GPU batch <= 2047). */
+int tdx_conv3x3_shape_ok(int B, int H, int W, int cin, int cout);
+/* Launch geometry a shape resolves to, bm*1000 + bn (introspection for tests: every tile
+ * template must be covered by a direct oracle check).  role 0: forward (and dgrad, called with
+ * the channel roles swapped), role 1: weight gradient. */
+int tdx_conv3x3_tile_shape(int B, int H, int W, int cin, int cout, int role);
 
 /* dx = d(conv3x3)/d(input) (autograd of diffusion.py:32-95 convolutions): the same implicit GEMM
  * with the roles of the channels swapped and the taps mirrored.
@@ -330,6 +339,11 @@ int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads
  * so that the gradients of the finished stages are final there.  (The caller orders `stream`
  * after its own compute stream as well.) */
 int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream);
+
+/* get_timestep_embedding(timesteps, embedding_dim), conditional_diffusion_laion.py:222-232:
+ * out[n][j] = sin(t_n f_j) for j < dim/2, cos(t_n f_{j-dim/2}) after, f_j = exp(-ln(1e4) j/(dim/2-1)),
+ * one trailing zero column when dim is odd.  out (B, dim) fp32. */
+int tdx_timestep_embedding(const int64_t* t, float* out, int B, int dim, tdx_stream_t stream);
 
 /* The time / class path on its own (diffusion.py:21-25, 105-113, 130-132;
  * conditional_diffusion.py:31, 121-125): emb = W2 silu(W1 float(t) + b1) + b2 [+ E[y]], then the

@@ -63,8 +63,19 @@ def test_laion_module_contract():
         m(torch.randn(2, 4, 32, 32).cuda(), torch.zeros(2, dtype=torch.long).cuda(), torch.randn(2, 512).cuda())
     with pytest.raises(Exception):
         m(torch.randn(2, 4, 32, 32), torch.zeros(2, dtype=torch.long), torch.randn(2, 768))  # CPU: no fallback
-    e = get_timestep_embedding(torch.tensor([0, 1, 999]), 768)
-    assert e.shape == (3, 768)
+    # the device kernel against the reference's own table (golden `sinusoid`) and, at other widths
+    # (even and odd), the oracle.  The frequency exp(.) may differ by 1 ulp between libm and the
+    # device, i.e. the argument t*f by up to 999 * 6e-8 = 6e-5: abs. tolerance 1.5e-4, exact at t = 0
+    from oracle import ref_laion as RL
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "laion_B8.npz"))
+    e = get_timestep_embedding(torch.tensor([0, 1, 999]).cuda(), 768)
+    assert e.shape == (3, 768) and e.dtype == torch.float32
+    assert (e.cpu() - torch.from_numpy(d["sinusoid"])).abs().max().item() < 1.5e-4
+    assert torch.equal(e[0].cpu(), torch.from_numpy(d["sinusoid"])[0])
+    for dim in (64, 65, 320):
+        tt = torch.tensor([0, 3, 250, 999])
+        got = get_timestep_embedding(tt.cuda(), dim).cpu()
+        assert got.shape == (4, dim) and (got - RL.timestep_embedding(tt, dim)).abs().max().item() < 1.5e-4, dim
 
 
 def test_laion_forward_matches_reference_golden(golden_dir):

@@ -56,7 +56,7 @@ def stream():
 
 
 def test_library_exports(tdx):
-    assert tdx.lib.tdx_version() == 100
+    assert tdx.lib.tdx_version() == 200
     maps = open("/proc/self/maps").read()
     assert "libtdx.so" in maps
 
@@ -128,7 +128,37 @@ CONV_CASES = [
     (4, 28, 64, 128), (2, 28, 128, 128), (3, 14, 128, 256), (3, 14, 256, 256), (5, 7, 256, 512),
     (3, 7, 512, 512), (7, 4, 512, 512), (3, 8, 1024, 256), (3, 8, 256, 256), (2, 16, 512, 128),
     (2, 16, 128, 128), (2, 32, 256, 64), (2, 32, 64, 64), (1, 7, 64, 64), (33, 28, 64, 128),
+    # shapes that resolve to the big tiles the B=256 benchmark launches (pick_tile / pick_wgrad):
+    (32, 16, 64, 512),    # forward 128x128, wgrad 128x64
+    (64, 16, 128, 128),   # forward and dgrad 128x64, wgrad 128x128
+    (256, 4, 512, 512),   # forward and dgrad 128x64 at the bottleneck shape of the benchmark
+    (32, 16, 512, 128),   # dgrad 128x128
+    (660, 7, 128, 128),   # ragged: 32340 rows = 252 full 128-row tiles + 84 rows, forward and dgrad 128x64
 ]
+# (case, role: 0 forward / 2 dgrad / 1 wgrad) -> tile that the library must pick for it; together
+# with the small cases (64x64 everywhere) every tile template has a direct oracle check
+BIG_TILE_EXPECT = {
+    ((32, 16, 64, 512), 0): 128128, ((32, 16, 64, 512), 1): 128064,
+    ((64, 16, 128, 128), 0): 128064, ((64, 16, 128, 128), 2): 128064, ((64, 16, 128, 128), 1): 128128,
+    ((256, 4, 512, 512), 0): 128064, ((256, 4, 512, 512), 2): 128064, ((256, 4, 512, 512), 1): 64064,
+    ((32, 16, 512, 128), 2): 128128, ((2, 32, 256, 64), 1): 64128,
+    ((660, 7, 128, 128), 0): 128064, ((660, 7, 128, 128), 2): 128064,
+}
+
+
+def test_conv_cases_cover_every_tile_template(tdx):
+    seen = set()
+    for (case, role), want in BIG_TILE_EXPECT.items():
+        B, H, cin, cout = case
+        if role == 2:    # dgrad = the forward kernel with the channel roles swapped
+            got = tdx.lib.tdx_conv3x3_tile_shape(B, H, H, cout, cin, 0)
+        else:
+            got = tdx.lib.tdx_conv3x3_tile_shape(B, H, H, cin, cout, role)
+        assert got == want, (case, role, got, want)
+        assert case in CONV_CASES
+        seen.add((role == 1, got))
+    assert {(False, 128128), (False, 128064), (True, 128128), (True, 128064), (True, 64128), (True, 64064)} <= seen
+    assert tdx.lib.tdx_conv3x3_tile_shape(4, 28, 28, 64, 128, 0) == 64064
 
 
 def _conv_inputs(B, H, cin, cout, seed=0):

@@ -72,6 +72,8 @@ _SIGS = {
     "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_stat_tile_rows": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_shape_ok": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_tile_shape": (C.c_int, [C.c_int] * 6),
     "tdx_conv3x3_wgrad": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _ptr, _ptr, _ptr]),
     "tdx_conv3x3_wgrad_reduce": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, C.c_int, _ptr]),
@@ -116,6 +118,7 @@ _SIGS = {
     "tdx_unet_backward_join": (C.c_int, [_ptr, _ptr]),
     "tdx_unet_eval_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
                                      _ptr, C.c_size_t, C.c_int, C.c_uint64, _ptr]),
+    "tdx_timestep_embedding": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_time_mlp_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
     "tdx_time_mlp_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int,
                                    _ptr]),

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib
 from .schedule import ForwardProcess as _ForwardProcess, sample_loop
 from .unet import ARCH_LAION, NoiseModelBase
 
@@ -20,17 +21,17 @@ TIME_DIM = ARCH_LAION.time_dim
 
 
 def get_timestep_embedding(timesteps, embedding_dim):
-    """conditional_diffusion_laion.py:222-232.  Host-side utility kept for API parity (the
-    model evaluates the same expression inside its time-embedding kernels)."""
-    half_dim = embedding_dim // 2
-    frequencies = torch.exp(
-        -torch.log(torch.tensor(10000.0))
-        * torch.arange(half_dim, dtype=torch.float32, device=timesteps.device) / (half_dim - 1))
-    embeddings = timesteps[:, None].float() * frequencies[None, :]
-    embeddings = torch.cat([torch.sin(embeddings), torch.cos(embeddings)], dim=-1)
-    if embedding_dim % 2 == 1:
-        embeddings = torch.cat([embeddings, torch.zeros_like(embeddings[:, :1])], dim=-1)
-    return embeddings
+    """conditional_diffusion_laion.py:222-232 on the device: ``tdx_timestep_embedding`` (the kernel
+    the model's own time path runs).  (N,) integer timesteps -> (N, embedding_dim) fp32."""
+    if not timesteps.is_cuda:
+        raise _lib.TdxError("get_timestep_embedding runs on the GPU only (no CPU fallback)")
+    t = timesteps.contiguous().to(torch.int64)
+    out = torch.empty((t.shape[0], int(embedding_dim)), dtype=torch.float32, device=t.device)
+    if t.shape[0]:
+        _lib.check(_lib.lib.tdx_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], int(embedding_dim),
+                                                   torch.cuda.current_stream(t.device).cuda_stream),
+                   "tdx_timestep_embedding")
+    return out
 
 
 class NoiseModel(NoiseModelBase):

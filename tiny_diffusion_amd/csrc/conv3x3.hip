@@ -849,6 +849,22 @@ extern "C" int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout
   return pick_tile((int64_t)B * H * W, cout).bm;
 }
 
+// Buffer descriptors address the input with 32-bit byte offsets and use offset 0x80000000 as the
+// "outside the image" sentinel that the hardware range check turns into zeros: the padded tensor
+// ((W+1) pixels of slack on both sides) must therefore stay below 2 GiB, or padding taps would
+// read real memory.  rows x ch floats, slack pixels of ch floats on each side.
+static bool descriptor_fits(int64_t rows, int ch, int64_t slack_px) {
+  return (rows * ch + 2 * slack_px * ch) * 4 < (1ll << 31);
+}
+
+extern "C" int tdx_conv3x3_shape_ok(int B, int H, int W, int cin, int cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
+  const int64_t M = (int64_t)B * H * W;
+  // forward reads (M, cin), dgrad reads (M, cout) through the same kernel; wgrad reads both
+  return descriptor_fits(M, cin, W + 1) && descriptor_fits(M, cout, W + 1) &&
+         (int64_t)cout * 9 * cin * 4 < (1ll << 31);
+}
+
 static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias, float* out,
                             int B, int H, int W, int cin, int cout, int flags,
                             const float* in_scale, const float* in_shift,
@@ -863,6 +879,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   if ((flags & TDX_CONV_OUT_STATS) && (flags & TDX_CONV_OUT_BNRELU)) return TDX_E_BADARG;
   int64_t M64 = (int64_t)B * H * W;
   if (M64 >= (1ll << 31)) return TDX_E_SHAPE;
+  if (!descriptor_fits(M64, cin, W + 1) || (int64_t)cout * 9 * cin * 4 >= (1ll << 31)) return TDX_E_SHAPE;
   ConvArgs a;
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
@@ -1302,6 +1319,18 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
   return c;
 }
 
+// which tile a shape resolves to (tests assert that every template is exercised):
+// role 0 = forward / dgrad-as-forward (channels as passed to tdx_conv3x3_fwd), 1 = wgrad; bm*1000 + bn
+extern "C" int tdx_conv3x3_tile_shape(int B, int H, int W, int cin, int cout, int role) {
+  const int64_t M = (int64_t)B * H * W;
+  if (role == 1) {
+    const WgradCfg c = pick_wgrad(M, cin, cout);
+    return c.bm * 1000 + c.bn;
+  }
+  const TileCfg c = pick_tile(M, cout);
+  return c.bm * 1000 + c.bn;
+}
+
 extern "C" int tdx_conv3x3_wgrad_splits(int B, int H, int W, int cin, int cout) {
   return pick_wgrad((int64_t)B * H * W, cin, cout).splits;
 }
@@ -1326,6 +1355,7 @@ extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_sla
   if (in_bn && (!in_scale || !in_shift)) return TDX_E_BADARG;
   int64_t M64 = (int64_t)B * H * W;
   if (M64 >= (1ll << 31) - 64) return TDX_E_SHAPE;
+  if (!descriptor_fits(M64, cin, W + 1) || !descriptor_fits(M64, cout, 0)) return TDX_E_SHAPE;
   WgradCfg c = pick_wgrad(M64, cin, cout);
   WgradArgs a;
   a.in = in; a.dy = dy; a.slabs = dw_slabs; a.in_scale = in_scale; a.in_shift = in_shift;

@@ -88,14 +88,25 @@ time_proj_kernel(const float* __restrict__ emb, const float* __restrict__ pw1,
 // ------------------------------------------------------------------ kind 1
 // sinusoid[n][j] = sin(t * f_j) for j < 384, cos(t * f_{j-384}) after;
 // f_j = exp(-ln(10000) * j / 383), every operation rounded to fp32 in the reference's order
-__global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B) {
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * TDL) return;
-  const int n = i / TDL, j = i - n * TDL, half = TDL / 2;
+  if (i >= B * dim) return;
+  const int n = i / dim, j = i - n * dim, half = dim / 2;
+  if (j >= 2 * half) { out[i] = 0.f; return; }  // odd width: one trailing zero column (reference :230-231)
   const int k = j < half ? j : j - half;
   const float f = expf(-logf(10000.0f) * (float)k / (float)(half - 1));
   const float a = (float)t[n] * f;
   out[i] = j < half ? sinf(a) : cosf(a);
+}
+
+// get_timestep_embedding(timesteps, embedding_dim), conditional_diffusion_laion.py:222-232, as an
+// entry point of its own (the model's forward runs the same kernel at dim = 768)
+extern "C" int tdx_timestep_embedding(const int64_t* t, float* out, int B, int dim, tdx_stream_t stream) {
+  if (!t || !out || B <= 0 || dim < 4) return TDX_E_BADARG;
+  if ((int64_t)B * dim >= (1ll << 31)) return TDX_E_SHAPE;
+  sinusoid_kernel<<<cdiv((int64_t)B * dim, 256), 256, 0, to_stream(stream)>>>(t, out, B, dim);
+  TDX_CHECK_LAUNCH();
+  return 0;
 }
 
 // out[n][o] = dot(W[o,:], act(in[n,:])) + b[o] (+ addend[n][o]);  rows of W are 256*R long.
@@ -157,7 +168,7 @@ static int time_embed_fwd_laion(const int64_t* t, const float* cond, const float
                                 hipStream_t st) {
   constexpr int NB = 4;
   const int gb = cdiv(B, NB);
-  sinusoid_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(t, sin, B);
+  sinusoid_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(t, sin, B, TDL);
   TDX_CHECK_LAUNCH();
   linear_rows_kernel<3, NB, false><<<dim3(gb, TDL / 64), 256, 0, st>>>(sin, P[TDX_P_TE0_W], P[TDX_P_TE0_B],
                                                                        nullptr, pre, B, TDL);

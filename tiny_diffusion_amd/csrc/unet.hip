@@ -164,6 +164,13 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2) return TDX_E_BADARG;
   if (kind == TDX_UNET_LAION && num_classes != 0) return TDX_E_BADARG;
   if (kind == TDX_UNET_LATENT_MLP && num_classes <= 0) return TDX_E_BADARG;
+  if (kind != TDX_UNET_LATENT_MLP) {
+    // every unit must be addressable at max_batch (32-bit buffer offsets: tdx_conv3x3_shape_ok)
+    const NetSpec& S = SPECS[kind];
+    for (int i = 0; i < 13; ++i)
+      if (!tdx_conv3x3_shape_ok(max_batch, S.units[i].hw, S.units[i].hw, S.units[i].cin, S.units[i].cout))
+        return TDX_E_SHAPE;
+  }
   tdx_unet* u = new (std::nothrow) tdx_unet();
   if (!u) return TDX_E_BADARG;
   u->max_batch = max_batch;

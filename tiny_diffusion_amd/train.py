@@ -66,12 +66,12 @@ class BucketedAllReduce:
     before the optimizer.  Works with any torch.distributed backend (RCCL on GPUs; gloo
     in the CPU tests)."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None):
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, enabled: bool = True):
         self.flat = flat_grad
         self.buckets = buckets
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (
-            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+            enabled and torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self._works = []
         # TDX_FORCE_ALLREDUCE=1 exercises the collective path on a single rank (testing)
         self.force = (os.environ.get("TDX_FORCE_ALLREDUCE") == "1" and torch.distributed.is_available()
@@ -105,7 +105,15 @@ class TrainStep:
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None,
                  max_grad_norm: Optional[float] = None, cosine_T_max: Optional[int] = None,
-                 cosine_eta_min: float = 0.0, use_graph: bool = False):
+                 cosine_eta_min: float = 0.0, use_graph: bool = False, data_parallel: bool = True):
+        """``data_parallel=False`` keeps the step rank-local even inside an initialised process group
+        (bench.py times it beside the collective step to report what the exchange costs).
+
+        BatchNorm running statistics are rank-local (each rank's forward updates its own from its
+        shard, as DistributedDataParallel does between its buffer broadcasts); ``sync_buffers()``
+        copies rank 0's to every rank - call it before saving a checkpoint or evaluating, so the
+        result does not depend on which rank saves (DDP's ``broadcast_buffers=True`` has that
+        effect at every forward)."""
         self.model = model
         # CosineAnnealingLR(optimizer, T_max, eta_min) stepped after every optimizer step
         self.base_lr, self.cosine_T_max, self.cosine_eta_min = lr, cosine_T_max, cosine_eta_min
@@ -122,8 +130,9 @@ class TrainStep:
         self.buckets = plan_buckets(self.offsets, model.num_classes > 0, bucket_floats, a.time_name, a.init_name,
                                     a.final_name)
         assert self.buckets[-1][0] == self.n_stages - 1
-        self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group)
+        self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group, enabled=data_parallel)
         self.world = self.reducer.world
+        self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
         self.comm = None  # communication stream (created on first use when there is a collective)
         # use_graph: capture the whole step (randint, q_sample, forward, loss, backward, clip, Adam)
         # into one HIP graph and replay it.  Single rank, noise and t drawn by torch inside the
@@ -177,6 +186,11 @@ class TrainStep:
             return self._graph_step(x_0, y)
         return self._eager_step(x_0, y, t, noise)
 
+    def _philox_offset(self) -> int:
+        """Philox stream of this (step, rank): ranks constructed with the same seed must not draw the
+        same noise for their shards (the global batch would hold ``world`` copies of every eps)."""
+        return self.step_count * self.world + self.rank
+
     def _adam_hyper(self, gscale: float):
         bc1 = 1.0 - self.betas[0] ** self.step_count
         bc2 = 1.0 - self.betas[1] ** self.step_count
@@ -220,7 +234,7 @@ class TrainStep:
         if t is None:
             t = torch.randint(0, fp.num_timesteps, (B,), device=dev)          # diffusion.py:220-222
         if noise is None and self.philox_seed is not None:
-            x_t, noise = fp.q_sample_philox(x_0, t, self.philox_seed, self.step_count)
+            x_t, noise = fp.q_sample_philox(x_0, t, self.philox_seed, self._philox_offset())
         else:
             x_t, noise = fp.q_sample(dev, x_0, t, noise=noise)                 # diffusion.py:225
         mode = MODE_TRAIN if m.training else MODE_EVAL_GRAD
@@ -260,14 +274,25 @@ class TrainStep:
                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_param.numel(),
                                         hyper.data_ptr(), self.betas[0], self.betas[1], self.eps, st),
                   "tdx_adam_step_dev")
+            m._buf_epoch += 1
             return self.loss
         check(lib.tdx_adam_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                 self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
                                 self.betas[1], self.eps, self.step_count, gscale, st),
               "tdx_adam_step")                                                 # diffusion.py:236
+        # the kernel wrote the parameters through raw pointers (no torch version bump): packed
+        # inference weights of every plan are stale now, whatever mode this step ran in
+        m._buf_epoch += 1
         if self.cosine_T_max is not None:
             self.lr = cosine_annealing_lr(self.step_count, self.base_lr, self.cosine_T_max, self.cosine_eta_min)
         return self.loss
+
+    def sync_buffers(self, src: int = 0):
+        """Rank ``src``'s BatchNorm running statistics on every rank (see the constructor's note)."""
+        if self.world > 1:
+            for b in self.model.buffers():
+                torch.distributed.broadcast(b, src, group=self.pg)
+            self.model._buf_epoch += 1
 
     def broadcast_parameters(self, src: int = 0):
         """Identical replicas at start (parameters and BN buffers)."""

@@ -12,6 +12,7 @@ There is no CPU/eager fallback: a non-CUDA input raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional
 
 import torch
@@ -168,7 +169,13 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, mode, x, t, y, *params):
         # grad mode is off inside Function.forward, so the caller decides the mode
+        if x.requires_grad:
+            # the reference's module is differentiable in x; this path stops at the parameters
+            # (the input gradient of initial_conv is never formed): refuse rather than return None
+            raise _lib.TdxError("x.requires_grad: libtdx computes parameter gradients only (no d/dx of the "
+                                "noise predictor); detach the input")
         out, plan, mode = module._run_forward(x, t, y, mode=mode)
+        module._live_ctx.add(ctx)   # weak: a graph dropped without backward() leaves by itself
         ctx.module = module
         ctx.plan = plan
         ctx.generation = plan.generation
@@ -185,7 +192,14 @@ class _UNetFunction(torch.autograd.Function):
                 "activations live in a per-batch-size workspace and were overwritten")
         flat, views = module._grad_buffers(d_out.device)
         module._run_backward(plan, d_out.contiguous(), views)
-        grads = tuple(views[name] for name in module._param_order)
+        # The gradients are views of ONE module-wide flat buffer.  With a single forward in the graph
+        # autograd copies them into p.grad before anything can overwrite the buffer; with several
+        # forwards of the same module in one graph (different batch sizes: the same size raises above)
+        # the next node's backward would overwrite them while they are still queued for accumulation,
+        # so they are detached from the buffer first.
+        shared = len(module._live_ctx) > 1
+        module._live_ctx.discard(ctx)
+        grads = tuple(views[name].clone() if shared else views[name] for name in module._param_order)
         return (None, None, None, None, None) + grads
 
 
@@ -221,6 +235,7 @@ class NoiseModelBase(nn.Module):
         self._grad_flat = None
         self._grad_views = None
         self._buf_epoch = 0
+        self._live_ctx = weakref.WeakSet()   # autograd nodes of this module whose backward has not run yet
 
     def _init_latent(self, arch, time_dim):
         # registration order == latent_diffusion.py:23-105
