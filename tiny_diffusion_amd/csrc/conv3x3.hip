@@ -710,6 +710,8 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "streams")) { g_tdx_streams = value; return 0; }
   if (!strcmp(key, "materialize")) { g_tdx_materialize = value; return 0; }
   if (!strcmp(key, "time_stage")) { g_tdx_time_stage = value; return 0; }
+  if (!strcmp(key, "time_l1_impl")) { g_tdx_time_l1_impl = value; return 0; }
+  if (!strcmp(key, "input_copy")) { g_tdx_input_copy = value; return 0; }
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }

@@ -354,6 +354,20 @@ extern "C" int tdx_probe_stream_copy(const float* src, float* dst, int64_t n, td
   return 0;
 }
 
+// plain device copy as a kernel on `st` (n floats, any alignment of n; pointers 4-byte aligned)
+__global__ void copy_floats_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+int tdx_copy_floats(const float* src, float* dst, size_t n, hipStream_t st) {
+  if (!src || !dst) return TDX_E_BADARG;
+  if (n == 0) return 0;
+  copy_floats_kernel<<<ew_grid((int64_t)n, 256), 256, 0, st>>>(src, dst, n);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_version(void) { return TDX_VERSION; }
 
 extern "C" const char* tdx_error_string(int code) {

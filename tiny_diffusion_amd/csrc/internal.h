@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 
+int tdx_copy_floats(const float* src, float* dst, size_t n, hipStream_t st);
 int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t st);
 int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
                         hipStream_t st);
@@ -44,7 +45,10 @@ int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int spli
 // tf: float(t) per sample, as stored by the forward (tdx_time_embed_fwd kind 0 -> sin, tdx_time_embed_only)
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
-                          const int* widths, float* scratch, int B, int ncls, hipStream_t st);
+                          const int* widths, float* scratch, int B, int ncls, hipStream_t st,
+                          const int64_t* t_i64 = nullptr);
+extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd_kernel (int64 t from the workspace copy)
+extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
                         float* tf_out, int B, hipStream_t st);
 // latent MLP noise model (latent_diffusion.py:16-128), kind TDX_UNET_LATENT_MLP of tdx_unet_*

@@ -261,6 +261,38 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
   }
 }
 
+// DIAGNOSTIC ONLY (knob time_l1_impl=1, tools/gpu_stage6_diag.py): the first version of the kernel
+// above, which converts the int64 step index inside its loop and reads it from the workspace copy of
+// t made by hipMemcpyAsync.  With the time path enqueued at backward stage 6 it produced a wrong
+// dW1 in some workgroups in round 1; kept so that the cause can be pinned down on
+// the GPU with the binary that showed it.
+__global__ void __launch_bounds__(256)
+time_l1_bwd_i64_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
+                       const int64_t* __restrict__ t, float* __restrict__ dw1, float* __restrict__ db1,
+                       int B) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
+  float sw = 0.f, sb = 0.f;
+#pragma unroll 4
+  for (int n = sl; n < B; n += 8) {
+    const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
+    sw = fmaf(gp, (float)t[n], sw);
+    sb += gp;
+  }
+  red[0][sl][cl] = sw;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0) {
+    sw = 0.f; sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sw += red[0][k][cl]; sb += red[1][k][cl]; }
+    dw1[j] = sw;
+    db1[j] = sb;
+  }
+}
+int g_tdx_time_l1_impl = 0;
+
 // g[i] *= silu'(pre[i])
 __global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,7 +351,8 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
 // (g_tk[n*ldg[k] + o], o < widths[k]).  scratch: g_emb (B*256) | h (B*256) | g_h (B*256)
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
-                          const int* widths, float* scratch, int B, int ncls, hipStream_t st) {
+                          const int* widths, float* scratch, int B, int ncls, hipStream_t st,
+                          const int64_t* t_i64) {
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * TD;
   float* g_h = scratch + (size_t)2 * B * TD;
@@ -342,7 +375,10 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
   TDX_CHECK_LAUNCH();
   lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0, TD);
   TDX_CHECK_LAUNCH();
-  time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  if (g_tdx_time_l1_impl == 1 && t_i64)
+    time_l1_bwd_i64_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  else
+    time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -354,8 +390,7 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
   if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int widths[3] = {128, 256, 512};
-  (void)t;
-  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st);
+  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t);
 }
 
 // emb only (kind-0 formula): the latent model applies its own projection widths

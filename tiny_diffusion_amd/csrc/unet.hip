@@ -130,6 +130,7 @@ Layout make_layout(const NetSpec& S, int B) {
 
 int g_tdx_materialize = 1;
 int g_tdx_time_stage = 14;  // backward stage after which the time/class path runs (14, or 6: see DESIGN.md 3.2)
+int g_tdx_input_copy = 0;
 int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
 
 struct tdx_unet {
@@ -301,6 +302,8 @@ extern "C" int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, s
       {"cat2", L.cat[1], b * sq(S.units[9].hw) * S.units[9].cin},
       {"cat1", L.cat[2], b * sq(S.units[11].hw) * S.units[11].cin},
       {"d1a", L.d1a, b * sq(S.out_hw) * 64}, {"emb", L.emb, b * S.time_dim},
+      {"t_copy", L.t, 2 * b}, {"tf", L.sin, b}, {"pre", L.pre, b * S.time_dim},
+      {"time_g_h", L.timescr + 2 * b * S.time_dim, b * S.time_dim},
       {"t1", L.tp[0], b * S.skip_ch[0]}, {"t2", L.tp[1], b * S.skip_ch[1]}, {"t3", L.tp[2], b * S.skip_ch[2]},
       {"G1", L.G1, L.gbuf}, {"G2", L.G2, L.gbuf}, {"G3", L.G3, L.gbuf}, {"G4", L.G4, L.gbuf},
       {"GS1", L.GS[0], b * sq(S.enc_hw[0]) * S.skip_ch[0]},
@@ -446,9 +449,15 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   else if (!u->packed) RC(pack_impl(u, params, buffers, stream));
   if (!infer) {
     // keep the inputs for backward (caller tensors may be gone by then)
-    TDX_HIP(hipMemcpyAsync(ws + L.x, x, (size_t)B * S.hw0 * S.hw0 * S.in_ch * sizeof(float), hipMemcpyDeviceToDevice, st));
-    TDX_HIP(hipMemcpyAsync(ws + L.t, t, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-    if (labels) TDX_HIP(hipMemcpyAsync(ws + L.y, labels, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    if (g_tdx_input_copy == 1) {
+      RC(tdx_copy_floats(x, ws + L.x, (size_t)B * S.hw0 * S.hw0 * S.in_ch, st));
+      RC(tdx_copy_floats(reinterpret_cast<const float*>(t), ws + L.t, 2 * (size_t)B, st));
+      if (labels) RC(tdx_copy_floats(reinterpret_cast<const float*>(labels), ws + L.y, 2 * (size_t)B, st));
+    } else {
+      TDX_HIP(hipMemcpyAsync(ws + L.x, x, (size_t)B * S.hw0 * S.hw0 * S.in_ch * sizeof(float), hipMemcpyDeviceToDevice, st));
+      TDX_HIP(hipMemcpyAsync(ws + L.t, t, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+      if (labels) TDX_HIP(hipMemcpyAsync(ws + L.y, labels, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    }
   }
 
   RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],

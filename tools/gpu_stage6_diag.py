@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Round-2 diagnosis of the round-1 `time_stage=6` anomaly (wrong time_embedding.0.weight gradient in
+some workgroups).  Runs the round-1 reproducer (fresh models, an old plan destroyed
+while the new one runs) with the ORIGINAL kernel (knob time_l1_impl=1: int64 t read from the
+workspace copy made by hipMemcpyAsync) and, for every mismatching iteration, recomputes dW1 on the
+host from the tensors the kernel read (g_h, pre) with
+    (a) the t of THIS iteration, (b) the t of earlier iterations (a stale read of the address),
+and reports which one reproduces the wrong 32-column groups.  Second arm: the same binary with the
+forward's input copies done by a copy KERNEL instead of hipMemcpyAsync (knob input_copy=1) - a
+host-side change only, so "any change to the kernel hides it" does not apply.
+
+    python tools/gpu_stage6_diag.py [B] [iters]
+"""
+import gc, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tiny_diffusion_amd._lib as L
+from tiny_diffusion_amd.diffusion import NoiseModel
+
+lib = L.lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+KEY = "time_embedding.0.weight"
+
+
+def fresh():
+    torch.manual_seed(1234)
+    return NoiseModel().cuda().train()
+
+
+def grads(m, x, t):
+    (m(x, t) ** 2).mean().backward()
+
+
+def silu_grad(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+def host_dw1(plan, tvals):
+    g_h = plan.tensor("time_g_h").view(B, 256).double().cpu()
+    pre = plan.tensor("pre").view(B, 256).double().cpu()
+    gp = g_h * silu_grad(pre)
+    return (gp * tvals.double().view(B, 1)).sum(0), gp.sum(0)
+
+
+def arm(name, l1_impl, input_copy, stage, destroy_while_running=True):
+    lib.tdx_tune_set(b"time_l1_impl", l1_impl)
+    lib.tdx_tune_set(b"input_copy", input_copy)
+    bad, report, t_hist = 0, [], []
+    for it in range(iters):
+        g = torch.Generator(device="cuda").manual_seed(it)
+        x = torch.randn(B, 1, 28, 28, device="cuda", generator=g)
+        t = torch.randint(0, 1000, (B,), device="cuda", generator=g)
+        lib.tdx_tune_set(b"time_stage", 14)
+        ref_m = fresh(); grads(ref_m, x, t); torch.cuda.synchronize()
+        ref = {k: p.grad.clone() for k, p in ref_m.named_parameters()}
+        del ref_m; gc.collect()
+        lib.tdx_tune_set(b"time_stage", stage)
+        a = fresh(); grads(a, x, t); torch.cuda.synchronize()
+        b = fresh()
+        grads(b, x, t)
+        if destroy_while_running:
+            del a; gc.collect()
+            torch.cuda.synchronize()
+        else:
+            torch.cuda.synchronize()
+            del a; gc.collect()
+        wrong = [k for k, p in b.named_parameters() if not torch.equal(p.grad, ref[k])]
+        if wrong:
+            bad += 1
+            plan = list(b._plans.values())[0]
+            got = dict(b.named_parameters())[KEY].grad.view(-1).double().cpu()
+            want = ref[KEY].view(-1).double().cpu()
+            cols = (got != want).nonzero().view(-1).tolist()
+            groups = sorted({c // 32 for c in cols})
+            t_copy = plan.tensor("t_copy").view(torch.int64)[:B].cpu()
+            entry = {"iter": it, "wrong_params": wrong, "wrong_groups": groups, "n_wrong_cols": len(cols),
+                     "t_copy_equals_t": bool(torch.equal(t_copy, t.cpu())),
+                     "tf_equals_t": bool(torch.equal(plan.tensor("tf")[:B].cpu(), t.cpu().float()))}
+            if cols:
+                cur, _ = host_dw1(plan, t.cpu())
+                scale = want.abs().max().item()
+                entry["host_with_current_t_matches_REFERENCE"] = float((cur - want).abs().max() / scale)
+                entry["host_with_current_t_vs_GOT_on_wrong_cols"] = float((cur[cols] - got[cols]).abs().max() / scale)
+                cands = {}
+                for back, told in enumerate(reversed(t_hist[-6:]), 1):
+                    old, _ = host_dw1(plan, told)
+                    cands[f"t_of_iter-{back}"] = float((old[cols] - got[cols]).abs().max() / scale)
+                entry["host_with_stale_t_vs_GOT_on_wrong_cols"] = cands
+                # any per-sample t' that explains got?  solve least squares gp @ t' = got on the wrong cols
+                g_h = plan.tensor("time_g_h").view(B, 256).double().cpu()
+                pre = plan.tensor("pre").view(B, 256).double().cpu()
+                gp = (g_h * silu_grad(pre))[:, cols]              # (B, ncols)
+                if len(cols) >= B:
+                    sol = torch.linalg.lstsq(gp.t(), got[cols].unsqueeze(1)).solution.view(-1)
+                    resid = (gp.t() @ sol - got[cols]).abs().max().item() / scale
+                    entry["lstsq_t_explaining_got"] = {"resid": resid, "t_fit_first8": sol[:8].tolist(),
+                                                       "t_true_first8": t.cpu()[:8].tolist(),
+                                                       "n_samples_differing": int(((sol - t.cpu().double()).abs() > 0.5).sum())}
+            report.append(entry)
+            print(f"[{name}] iter {it}: BAD {json.dumps(entry)}", flush=True)
+        elif it % 20 == 0:
+            print(f"[{name}] iter {it}: ok", flush=True)
+        t_hist.append(t.cpu())
+        del b; gc.collect()
+    print(f"[{name}] done: {bad} bad of {iters}", flush=True)
+    return {"arm": name, "bad": bad, "iters": iters, "report": report}
+
+
+out = [arm("old-kernel+hipMemcpyAsync, stage 6", 1, 0, 6),
+       arm("old-kernel+copy-kernel, stage 6", 1, 1, 6),
+       arm("old-kernel+hipMemcpyAsync, stage 6, old plan destroyed only after the sync", 1, 0, 6, False),
+       arm("current-kernel+hipMemcpyAsync, stage 6", 0, 0, 6)]
+lib.tdx_tune_set(b"time_stage", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/stage6_diag.json", "w"), indent=1)
+print(json.dumps([{k: v for k, v in o.items() if k != "report"} for o in out]))
