@@ -385,6 +385,10 @@ int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const* buffers,
  * (one / two register stages); "splitk" 0 | 1. */
 int tdx_tune_set(const char* key, int value);
 
+/* Diagnostics (tools/gpu_stage6_diag.py): device buffer that the instrumented variant of the time-path
+ * kernel (knob "time_l1_impl" = 2) records its loads into; NULL disables it. */
+int tdx_diag_set_buffer(void* device_buffer);
+
 /* Peak probes used by bench.py for measured roofline denominators. */
 int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream);
 int tdx_probe_stream_copy(const float* src, float* dst, int64_t n, tdx_stream_t stream);

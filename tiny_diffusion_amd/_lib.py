@@ -127,6 +127,7 @@ _SIGS = {
     "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
     "tdx_unet_tensor": (C.c_int, [_ptr, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tdx_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "tdx_diag_set_buffer": (C.c_int, [_ptr]),
     "tdx_probe_mfma_f32": (C.c_int, [_ptr, C.c_int, C.c_int, _ptr]),
     "tdx_probe_stream_copy": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
 }

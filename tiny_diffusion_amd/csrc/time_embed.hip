@@ -291,7 +291,47 @@ time_l1_bwd_i64_kernel(const float* __restrict__ g_h, const float* __restrict__ 
     db1[j] = sb;
   }
 }
+// DIAGNOSTIC ONLY (time_l1_impl=2): the same loop, additionally recording what it loaded:
+// dbg[0..7] per workgroup = {t pointer lo, hi, XCC id, s_memrealtime lo at start, at end, B, 0, 0} then,
+// from dbg + 64*8 on, the raw int64 each (workgroup, slice, k) read, as two dwords.
+__global__ void __launch_bounds__(256)
+time_l1_bwd_i64_dbg_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
+                           const int64_t* __restrict__ t, float* __restrict__ dw1, float* __restrict__ db1,
+                           int B, unsigned* __restrict__ dbg) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
+  const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  float sw = 0.f, sb = 0.f;
+  unsigned* seen = dbg + 64 * 8 + (size_t)blockIdx.x * (2 * 1024);  // up to 1024 samples per workgroup
+#pragma unroll 4
+  for (int n = sl; n < B; n += 8) {
+    const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
+    const int64_t tv = t[n];
+    if (cl == 0 && n < 1024) { seen[2 * n] = (unsigned)tv; seen[2 * n + 1] = (unsigned)((uint64_t)tv >> 32); }
+    sw = fmaf(gp, (float)tv, sw);
+    sb += gp;
+  }
+  red[0][sl][cl] = sw;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0) {
+    sw = 0.f; sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sw += red[0][k][cl]; sb += red[1][k][cl]; }
+    dw1[j] = sw;
+    db1[j] = sb;
+  }
+  if (threadIdx.x == 0) {
+    unsigned* h = dbg + blockIdx.x * 8;
+    h[0] = (unsigned)(uintptr_t)t; h[1] = (unsigned)((uintptr_t)t >> 32);
+    h[2] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID, bits 3:0
+    h[3] = t0; h[4] = (unsigned)__builtin_amdgcn_s_memrealtime(); h[5] = (unsigned)B;
+  }
+}
 int g_tdx_time_l1_impl = 0;
+unsigned* g_tdx_diag_buffer = nullptr;  // >= (64*8 + 8*2048) dwords, set by tdx_diag_set_buffer
+extern "C" int tdx_diag_set_buffer(void* p) { g_tdx_diag_buffer = static_cast<unsigned*>(p); return 0; }
 
 // g[i] *= silu'(pre[i])
 __global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n) {
@@ -375,7 +415,10 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
   TDX_CHECK_LAUNCH();
   lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0, TD);
   TDX_CHECK_LAUNCH();
-  if (g_tdx_time_l1_impl == 1 && t_i64)
+  if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer)
+    time_l1_bwd_i64_dbg_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B,
+                                                        g_tdx_diag_buffer);
+  else if (g_tdx_time_l1_impl == 1 && t_i64)
     time_l1_bwd_i64_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   else
     time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);

@@ -98,8 +98,12 @@ def arm(name, l1_impl, input_copy, stage, destroy_while_running=True):
                     entry["lstsq_t_explaining_got"] = {"resid": resid, "t_fit_first8": sol[:8].tolist(),
                                                        "t_true_first8": t.cpu()[:8].tolist(),
                                                        "n_samples_differing": int(((sol - t.cpu().double()).abs() > 0.5).sum())}
+            if l1_impl == 2:
+                entry["kernel_saw"] = DUMP(t.cpu())
             report.append(entry)
             print(f"[{name}] iter {it}: BAD {json.dumps(entry)}", flush=True)
+        elif l1_impl == 2 and it == 1:
+            print(f"[{name}] iter {it}: ok; kernel saw {json.dumps(DUMP(t.cpu()))}", flush=True)
         elif it % 20 == 0:
             print(f"[{name}] iter {it}: ok", flush=True)
         t_hist.append(t.cpu())
@@ -108,11 +112,33 @@ def arm(name, l1_impl, input_copy, stage, destroy_while_running=True):
     return {"arm": name, "bad": bad, "iters": iters, "report": report}
 
 
-out = [arm("old-kernel+hipMemcpyAsync, stage 6", 1, 0, 6),
-       arm("old-kernel+copy-kernel, stage 6", 1, 1, 6),
-       arm("old-kernel+hipMemcpyAsync, stage 6, old plan destroyed only after the sync", 1, 0, 6, False),
-       arm("current-kernel+hipMemcpyAsync, stage 6", 0, 0, 6)]
-lib.tdx_tune_set(b"time_stage", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
+# instrumented variant first: what did the kernel actually load?
+dbg = torch.zeros(64 * 8 + 8 * 2048, dtype=torch.int32, device="cuda")
+lib.tdx_diag_set_buffer(dbg.data_ptr())
+
+
+def dump_seen(t_true):
+    d = dbg.cpu()
+    hdr = d[:64].view(8, 8)
+    seen = d[64 * 8:].view(8, 1024, 2)[:, :B]
+    vals = (seen[..., 0].to(torch.int64) & 0xffffffff) | (seen[..., 1].to(torch.int64) << 32)
+    out = {"t_ptr": [hex(((int(h[1]) & 0xffffffff) << 32) | (int(h[0]) & 0xffffffff)) for h in hdr],
+           "xcc": [int(h[2]) for h in hdr], "t_start": [int(h[3]) & 0xffffffff for h in hdr],
+           "t_end": [int(h[4]) & 0xffffffff for h in hdr], "B_seen": [int(h[5]) for h in hdr], "wrong": []}
+    for wg in range(8):
+        bad_n = (vals[wg] != t_true).nonzero().view(-1).tolist()
+        if bad_n:
+            out["wrong"].append({"wg": wg, "n": bad_n[:16], "count": len(bad_n),
+                                 "seen_hex": [hex(int(vals[wg, n]) & 0xffffffffffffffff) for n in bad_n[:16]],
+                                 "true": [int(t_true[n]) for n in bad_n[:16]]})
+    return out
+
+
+DUMP = dump_seen
+out = [arm("instrumented old kernel, stage 6", 2, 0, 6),
+       arm("old-kernel+hipMemcpyAsync, stage 6", 1, 0, 6),
+       ]
+lib.tdx_diag_set_buffer(None); lib.tdx_tune_set(b"time_stage", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/stage6_diag.json", "w"), indent=1)
 print(json.dumps([{k: v for k, v in o.items() if k != "report"} for o in out]))
