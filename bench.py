@@ -143,6 +143,39 @@ def roofline_block(B: int):
     }
 
 
+def usable_cores() -> int:
+    """CPU threads this process may actually use: the affinity mask and the cgroup quota, not
+    os.cpu_count() (the GPU box shows every core of the host but gives a job the share of its GPU -
+    16 threads per GPU on this pool; oversubscribing that 10x makes a torch CPU step crawl).
+    TDX_BENCH_THREADS overrides."""
+    if os.environ.get("TDX_BENCH_THREADS"):
+        return max(1, int(os.environ["TDX_BENCH_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16 * max(1, torch.cuda.device_count()))   # the pool's CPU share per GPU
+
+
+def note(msg: str):
+    """Progress on stderr (the JSON line on stdout stays the only stdout output)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -163,7 +196,7 @@ def cpu_baseline(batch: int = 64, steps: int = 10, warm: int = 2, sample_steps: 
     from oracle import ref_cpu as R
     from oracle.weights import make_state_dict
 
-    threads = max(1, os.cpu_count() or 1)
+    threads = usable_cores()
     torch.set_num_threads(threads)
     sd = make_state_dict(0, False)
     sched = R.Schedule()
@@ -197,7 +230,7 @@ def cpu_baseline(batch: int = 64, steps: int = 10, warm: int = 2, sample_steps: 
             stimes.append(time.perf_counter() - t0)
     sdt = sum(stimes[warm:]) / sample_steps
     return {"value": round(batch / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "host_cpu_count": os.cpu_count(),
             "sample": f"{steps} train steps at B={batch} (configs[0]) after {warm} warm-up, oracle/ref_cpu.py; "
                       f"{sample_steps} reverse steps at n={batch} after {warm} warm-up",
             "train_ms_per_step": round(dt * 1e3, 1),
@@ -319,7 +352,7 @@ def first_step_parity(model, fp, x0, seed: int):
     eps, _, _ = model._run_forward(x_t, t, None, mode=MODE_TRAIN)
     torch.cuda.synchronize()
     p, b = R.split_state(sd)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         ref = R.unet_forward(p, b, x_t.cpu(), t.cpu(), training=True)
     d = eps.cpu().double() - ref.double()
@@ -530,7 +563,9 @@ def main():
 
     parity = None
     if rank == 0 and not args.train_only:
+        note("first-step parity check against the CPU oracle (B=256 forward on the host) ...")
         parity = first_step_parity(model, fp, x0, 1234)   # untimed; the other ranks wait at the barrier
+        note(f"parity ok: {parity}")
     dt, loss = timed_steps(ts, x0, args.warmup, args.steps, barrier)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -585,16 +620,21 @@ def main():
                 "note": "single_rank = the same step with the gradient all-reduce disabled, timed on all "
                         f"{world} GPUs at once after the main region (mean over ranks); backend " + backend}
         if not args.no_extras and not args.train_only and world == 1:
+            note(f"train: {value:.0f} images/s, {ms_per_step:.3f} ms/step; peak probes ...")
             probes = peak_probes()
+            note(f"probes {probes}; conv roofline leg ...")
             res["roofline"] = roofline_block(PER_GPU_BATCH)
             res["roofline"]["peak_measured"] = probes["mfma_f32_tflops"]
             res["roofline"]["frac_of_measured_peak"] = round(res["roofline"]["achieved"] / probes["mfma_f32_tflops"], 4)
             res["roofline"]["whole_step_frac"] = round(
                 value * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             res["roofline"]["in_situ"] = in_situ()
+            note("HBM-bound kernels ...")
             res["hbm_bound_kernels"] = {"peak_tbps": PEAK_HBM_TBPS, "peak_measured_copy_tbps": probes["hbm_copy_tbps"],
                                         "kernels": hbm_kernels(PER_GPU_BATCH, probes["hbm_copy_tbps"])}
+            note(f"CPU baseline on {usable_cores()} threads ...")
             res["cpu_baseline"] = cpu_baseline()
+            note(f"cpu baseline {res['cpu_baseline']['value']} images/s; sampling chains ...")
             model.eval()
             s16, s64 = sample_latency(model, fp, 16), sample_latency(model, fp, 64)
             fwd = TRAIN_FLOP_PER_IMAGE / 3.0  # forward FLOPs per image and step
@@ -603,8 +643,11 @@ def main():
                              "n16_tflops": round(16 * 1000 * fwd / s16 / 1e12, 1),
                              "n64_tflops": round(64 * 1000 * fwd / s64 / 1e12, 1),
                              "cpu_n64_extrapolated_s": res["cpu_baseline"]["sample_chain_s_n64_extrapolated"]}
+            note("LAION leg ...")
             res["laion_unet"] = laion_extras()
+            note("latent MLP leg ...")
             res["latent_mlp"] = latent_extras()
+            note("done")
         print(json.dumps(res), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()

@@ -106,6 +106,18 @@ int tdx_adam_step_dev(float* param, const float* grad, float* exp_avg, float* ex
                       int64_t n, const float* hyper, float beta1, float beta2, float eps,
                       tdx_stream_t stream);
 
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) + Adam (conditional_diffusion_laion.py:469-472) fused:
+ * a fixed-order sum of squares of the flat gradient, then the Adam pass applies
+ *   g * grad_scale * min(1, max_norm / (sqrt(sum g^2) * |grad_scale| + 1e-6))
+ * on the fly (the clipped gradient is never written back).  hyper_dev: NULL, or the three device
+ * floats of tdx_adam_step_dev (then lr / step / grad_scale are ignored): graph-capturable.
+ * scratch: tdx_adam_clip_scratch_bytes() bytes of device memory, 8-byte aligned. */
+size_t tdx_adam_clip_scratch_bytes(void);
+int tdx_adam_step_clip(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                       float grad_scale, float max_norm, const float* hyper_dev, void* scratch,
+                       tdx_stream_t stream);
+
 /* ---- building blocks (exported for unit tests and re-use) --------------- */
 
 /* OIHW (Cout,Cin,3,3) -> forward pack [Cout][9][Cin] and dgrad pack
@@ -170,6 +182,25 @@ int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_slabs,
                       const float* in_scale, const float* in_shift, tdx_stream_t stream);
 int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, int cout, int cin,
                              tdx_stream_t stream);
+
+/* ---- bf16 compute mode (opt-in; BASELINE.json configs[3]/[4]; the reference is fp32-only) --------
+ * The same three GEMMs on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.
+ * Tensors stay fp32 in memory; the MFMA operands are rounded to bf16 (nearest even) while a tile is
+ * staged, weights are packed to bf16 by tdx_pack_conv3x3_bf16 ([cout][9][cin] / [cin][9][cout], 2 bytes
+ * per element).  Arguments as tdx_conv3x3_fwd / _wgrad; cin % 64 == 0, cout % 64 == 0; statistics
+ * tiles are always tdx_conv3x3_bf16_stat_tile_rows() = 128 pixels; slabs / splits / reduce are those
+ * of the fp32 weight gradient.  Tolerance: tests/test_gpu_bf16.py. */
+int tdx_pack_conv3x3_bf16(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin,
+                          tdx_stream_t stream);
+int tdx_conv3x3_bf16_stat_tile_rows(void);
+int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const float* bias, float* out,
+                         int B, int H, int W, int cin, int cout, int flags,
+                         const float* in_scale, const float* in_shift,
+                         const float* out_scale, const float* out_shift,
+                         float* stats_partial, tdx_stream_t stream);
+int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* dw_slabs,
+                           int B, int H, int W, int cin, int cout, int flags,
+                           const float* in_scale, const float* in_shift, tdx_stream_t stream);
 
 /* BatchNorm2d (diffusion.py:34 ...): turn the conv epilogue's partials into
  * per-channel scale/shift (+ saved mean/rstd) and update the running buffers.
@@ -308,6 +339,17 @@ int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes);
  *   TDX_P_INIT_* / TDX_P_FINAL_*; x and out are (B,20). */
 enum { TDX_UNET_MNIST = 0, TDX_UNET_LAION = 1, TDX_UNET_LATENT_MLP = 2 };
 int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes);
+/* The same with an explicit input resolution hw x hw (0 = the reference's: 28 for kind 0, 32 for
+ * kind 1).  The LAION network is fully convolutional (conditional_diffusion_laion.py:304-332): any
+ * multiple of 8 from 32 to 512 is accepted (64 = BASELINE.json configs[4]); the MNIST network resizes
+ * to fixed sizes and takes 28 only.  TDX_E_SHAPE otherwise. */
+int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int num_classes, int hw);
+/* Arithmetic of the plan's 3x3 convolutions: TDX_PREC_F32 (default: exact fp32 MFMA) or TDX_PREC_BF16
+ * (bf16 operands, fp32 accumulation and storage; see the bf16 section above).  Call before a forward;
+ * a backward must run in the precision of its forward (TDX_E_STATE otherwise).  Not for kind 2. */
+#define TDX_PREC_F32 0
+#define TDX_PREC_BF16 1
+int tdx_unet_set_precision(tdx_unet* u, int precision);
 int tdx_unet_destroy(tdx_unet* u);
 size_t tdx_unet_workspace_bytes(const tdx_unet* u, int batch, int mode);
 

@@ -151,7 +151,12 @@ def bilinear_ac(x, size):
     return t * hl0.view(1, 1, -1, 1) + b * hl1.view(1, 1, -1, 1)
 
 
-def conv_bn_relu(x, p, prefix_conv, prefix_bn, training, buffers):
+def conv_bn_relu(x, p, prefix_conv, prefix_bn, training, buffers, relu_mask=None, taps=None):
+    """conv3x3 -> BatchNorm2d -> ReLU.  ``relu_mask`` (bool, NCHW) overrides the sign test of the
+    ReLU: tests use it to evaluate the oracle with the SAME active set as the implementation under
+    test - an activation within fp32 rounding of 0 is a coin flip (its value is ~0 either way, but
+    its gradient path is on or off), and either choice is a valid sub-gradient of max(0, .).
+    ``taps`` (dict) receives the normalised pre-activation under the key ``prefix_bn``."""
     y = F.conv2d(x, p[f"{prefix_conv}.weight"], p[f"{prefix_conv}.bias"], padding=1)
     y = batchnorm2d(
         y,
@@ -162,13 +167,18 @@ def conv_bn_relu(x, p, prefix_conv, prefix_bn, training, buffers):
         training,
         buffers.get(f"{prefix_bn}.num_batches_tracked"),
     )
+    if taps is not None:
+        taps["prebn_act:" + prefix_bn] = y
+    if relu_mask is not None:
+        return y * relu_mask.to(y.dtype)
     return F.relu(y)
 
 
-def stage(x, p, name, training, buffers):
+def stage(x, p, name, training, buffers, relu_masks=None, taps=None):
     """[conv3x3 -> BN -> ReLU] x2, diffusion.py:32-39 and siblings."""
-    x = conv_bn_relu(x, p, f"{name}.0", f"{name}.1", training, buffers)
-    return conv_bn_relu(x, p, f"{name}.3", f"{name}.4", training, buffers)
+    rm = relu_masks or {}
+    x = conv_bn_relu(x, p, f"{name}.0", f"{name}.1", training, buffers, rm.get(f"{name}.1"), taps)
+    return conv_bn_relu(x, p, f"{name}.3", f"{name}.4", training, buffers, rm.get(f"{name}.4"), taps)
 
 
 def time_embedding(p, t, y=None):
@@ -197,12 +207,15 @@ def split_state(sd):
     return params, buffers
 
 
-def unet_forward(p, buffers, x, t, y=None, training=False, taps=None, pool_idx=None):
+def unet_forward(p, buffers, x, t, y=None, training=False, taps=None, pool_idx=None, relu_masks=None):
     """NoiseModel.forward, diffusion.py:109-162 / conditional_diffusion.py:115-172.
 
     ``p``: parameter dict; ``buffers``: BN buffers (updated in place when
     training).  ``taps`` (optional dict) receives every named intermediate.
+    ``pool_idx`` / ``relu_masks``: sub-gradient choices of the implementation under test
+    (maxpool2_ceil, conv_bn_relu); keys "e1".."e3" / BatchNorm module names ("enc1.1", ...).
     """
+    rm = relu_masks
 
     def tap(name, v):
         if taps is not None:
@@ -211,14 +224,15 @@ def unet_forward(p, buffers, x, t, y=None, training=False, taps=None, pool_idx=N
 
     emb = tap("emb", time_embedding(p, t, y))
     x0 = tap("x0", F.conv2d(x, p["initial_conv.weight"], p["initial_conv.bias"], padding=1))
-    e1 = tap("e1", stage(x0, p, "enc1", training, buffers))
+    e1 = tap("e1", stage(x0, p, "enc1", training, buffers, rm, taps))
     pool_idx = pool_idx or {}
     e1p = tap("e1p", maxpool2_ceil(e1, pool_idx.get("e1")))
-    e2 = tap("e2", stage(e1p, p, "enc2", training, buffers))
+    e2 = tap("e2", stage(e1p, p, "enc2", training, buffers, rm, taps))
     e2p = tap("e2p", maxpool2_ceil(e2, pool_idx.get("e2")))
-    e3 = tap("e3", stage(e2p, p, "enc3", training, buffers))
+    e3 = tap("e3", stage(e2p, p, "enc3", training, buffers, rm, taps))
     e3p = tap("e3p", maxpool2_ceil(e3, pool_idx.get("e3")))
-    b = tap("b", conv_bn_relu(e3p, p, "bottleneck.0", "bottleneck.1", training, buffers))
+    b = tap("b", conv_bn_relu(e3p, p, "bottleneck.0", "bottleneck.1", training, buffers,
+                              (rm or {}).get("bottleneck.1"), taps))
 
     # 1x1 conv on a (B,256,1,1) map == linear, diffusion.py:130-132
     def proj(k):
@@ -231,20 +245,20 @@ def unet_forward(p, buffers, x, t, y=None, training=False, taps=None, pool_idx=N
 
     up_b = tap("up_b", bilinear_ac(b, (8, 8)))
     e3a = tap("e3a", bilinear_ac(e3 + t3, (8, 8)))
-    d3 = tap("d3", stage(torch.cat([up_b, e3a], dim=1), p, "dec3", training, buffers))
+    d3 = tap("d3", stage(torch.cat([up_b, e3a], dim=1), p, "dec3", training, buffers, rm, taps))
     up_d3 = tap("up_d3", bilinear_ac(d3, (16, 16)))
     e2a = tap("e2a", bilinear_ac(e2 + t2, (16, 16)))
-    d2 = tap("d2", stage(torch.cat([up_d3, e2a], dim=1), p, "dec2", training, buffers))
+    d2 = tap("d2", stage(torch.cat([up_d3, e2a], dim=1), p, "dec2", training, buffers, rm, taps))
     up_d2 = tap("up_d2", bilinear_ac(d2, (32, 32)))
     e1a = tap("e1a", bilinear_ac(e1 + t1, (32, 32)))
-    d1 = tap("d1", stage(torch.cat([up_d2, e1a], dim=1), p, "dec1", training, buffers))
+    d1 = tap("d1", stage(torch.cat([up_d2, e1a], dim=1), p, "dec1", training, buffers, rm, taps))
     d1a = tap("d1a", bilinear_ac(d1, (28, 28)))
     out = F.conv2d(d1a, p["final_conv.weight"], p["final_conv.bias"], padding=1)
     return tap("out", out)
 
 
 def train_step_grads(sd, x_t, t, noise, y=None, training=True, dtype=torch.float32, pool_idx=None,
-                     taps=None):
+                     taps=None, relu_masks=None):
     """Forward + MSE + backward (diffusion.py:228-235) on the oracle.
 
     Returns (loss, eps_hat, grads dict, updated buffers).  ``dtype=torch.float64``
@@ -257,7 +271,8 @@ def train_step_grads(sd, x_t, t, noise, y=None, training=True, dtype=torch.float
         buffers = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v) for k, v in buffers.items())
         x_t, noise = x_t.to(dtype), noise.to(dtype)
     leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
-    eps_hat = unet_forward(leaves, buffers, x_t, t, y, training=training, taps=taps, pool_idx=pool_idx)
+    eps_hat = unet_forward(leaves, buffers, x_t, t, y, training=training, taps=taps, pool_idx=pool_idx,
+                           relu_masks=relu_masks)
     loss = F.mse_loss(eps_hat, noise)
     grads = torch.autograd.grad(loss, list(leaves.values()))
     return loss.detach(), eps_hat.detach(), OrderedDict(zip(leaves.keys(), grads)), buffers

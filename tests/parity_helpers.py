@@ -40,11 +40,53 @@ def gpu_pool_routing(m, B, cpu_args, training=True):
         idx64 = w64.argmax(dim=-1, keepdim=True)
         differ = (idx != idx64).squeeze(-1)
         if differ.any():
-            top2 = w64[differ].topk(2, dim=-1).values
-            gap = ((top2[:, 0] - top2[:, 1]) / top2[:, 0].abs().clamp_min(1e-30))
+            # a tie = the exact values of the entry the GPU picked and of the exact arg-max agree to 1e-4
+            # of the larger of |value| and the tensor's RMS (relative to the value alone, a window whose
+            # entries are all ~0 after the ReLU - exact maximum 1e-9 - would count as a gap of 100 %)
+            rms = taps[name].pow(2).mean().sqrt().item()
+            picked = torch.gather(w64, -1, idx)[differ].squeeze(-1)
+            best = w64[differ].max(dim=-1).values
+            gap = (best - picked) / torch.maximum(best.abs(), torch.tensor(rms, dtype=best.dtype))
             assert gap.max().item() < 1e-4, (name, int(differ.sum()), gap.max().item())
         out[name] = idx
     return out
+
+
+UNIT_BN = ("enc1.1", "enc1.4", "enc2.1", "enc2.4", "enc3.1", "enc3.4", "bottleneck.1",
+           "dec3.1", "dec3.4", "dec2.1", "dec2.4", "dec1.1", "dec1.4")
+UNIT_SHAPE = ((28, 128), (28, 128), (14, 256), (14, 256), (7, 512), (7, 512), (4, 512),
+              (8, 256), (8, 256), (16, 128), (16, 128), (32, 64), (32, 64))
+
+
+def gpu_relu_masks(m, B, cpu_args, training=True, pool_idx=None, tol=1e-5):
+    """Active set of every ReLU as the GPU forward decided it (sign of y*scale+shift from its own
+    pre-BN tensors), keyed by BatchNorm module name for ``R.unet_forward(relu_masks=...)``.
+    Checked against the exact (fp64) pre-activations: the sets may differ only where the exact
+    normalised value is within ``tol`` of 0 relative to the layer's RMS - there the activation is 0
+    to rounding either way and on/off are both valid sub-gradients."""
+    plan = [p for (dev, b), p in m._plans.items() if b == B][0]
+    sd, x, t, noise, y = cpu_args
+    p64, b64 = R.split_state(sd)
+    p64 = {k: v.double() for k, v in p64.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in b64.items()}
+    taps = {}
+    with torch.no_grad():
+        R.unet_forward(p64, b64, x.double(), t, y, training=training, taps=taps, pool_idx=pool_idx)
+    masks, flips = {}, {}
+    for u, (name, (H, Cc)) in enumerate(zip(UNIT_BN, UNIT_SHAPE)):
+        Y = plan.tensor(f"Y{u}").view(B, H, H, Cc)
+        ss = plan.tensor(f"ss{u}")
+        act = torch.addcmul(ss[Cc:2 * Cc], Y, ss[:Cc]).permute(0, 3, 1, 2).cpu()
+        mask = act > 0
+        exact = taps["prebn_act:" + name]
+        differ = mask != (exact > 0)
+        if differ.any():
+            rms = exact.pow(2).mean().sqrt().item()
+            worst = (exact[differ].abs().max() / rms).item()
+            assert worst < tol, (name, int(differ.sum()), worst)
+            flips[name] = int(differ.sum())
+        masks[name] = mask
+    return masks, flips
 
 
 def grad_precision_failures(got, g32, g64, training, k_factor=10.0, floor=1e-4):

@@ -8,10 +8,13 @@ on the 1-GPU box), and RCCL ("nccl") with one rank per GPU (runs wherever >= 2 G
 skips otherwise).
 
 Gate: the single-GPU gradient gate of test_gpu_unet.py.  Every rank evaluates the oracle on ITS shard
-in fp32 and in fp64 with the max-pool routing its GPU forward chose (near-tied window entries are
-an fp32 coin flip), the per-shard oracle gradients are averaged over ranks, and the all-reduced GPU
-gradient must be as close to the fp64 mean as 10x the fp32 oracle's own distance from it (floor
-1e-4 per parameter)."""
+in fp32 and in fp64 with the sub-gradient choices its GPU forward made - the max-pool routing and
+the ReLU active sets (a window tie or an activation within fp32 rounding of 0 is a coin flip, and
+at B = 8 per shard ONE flipped ReLU in a deep layer moves that layer's gradient by 5e-3 through
+train-mode BatchNorm: measured in round 2, tools/gpu_ddp_debug.py - with the GPU's choices the fp64
+oracle agrees with the GPU to 5e-6).  The per-shard oracle gradients are averaged over ranks, and
+the all-reduced GPU gradient must be as close to the fp64 mean as 10x the fp32 oracle's own distance
+from it (floor 1e-4 per parameter)."""
 import os
 import socket
 
@@ -55,7 +58,7 @@ def _worker(rank, world, port, out, backend):
     try:
         from oracle import ref_cpu as R
         from oracle.weights import make_state_dict
-        from parity_helpers import gpu_pool_routing, grad_precision_failures
+        from parity_helpers import gpu_pool_routing, gpu_relu_masks, grad_precision_failures
         from tiny_diffusion_amd.conditional_diffusion import ForwardProcess, NoiseModel
         from tiny_diffusion_amd.train import TrainStep
 
@@ -76,8 +79,9 @@ def _worker(rank, world, port, out, backend):
         x_t = R.q_sample(R.Schedule(), x0, t, noise)
         cpu_args = (sd, x_t, t, noise, y)
         pidx = gpu_pool_routing(m, B, cpu_args)
-        _, _, g32, _ = R.train_step_grads(*cpu_args, pool_idx=pidx)
-        _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, pool_idx=pidx)
+        masks, _ = gpu_relu_masks(m, B, cpu_args, pool_idx=pidx)
+        _, _, g32, _ = R.train_step_grads(*cpu_args, pool_idx=pidx, relu_masks=masks)
+        _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, pool_idx=pidx, relu_masks=masks)
         names = list(ts.offsets)
         f32 = torch.cat([g32[k].reshape(-1).double() for k in names])
         f64 = torch.cat([g64[k].reshape(-1) for k in names])

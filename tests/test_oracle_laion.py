@@ -59,3 +59,33 @@ def test_laion_oracle_matches_reference(golden_dir):
     x = RL.sample_chain(sd, R.Schedule(num_timesteps=T), torch.from_numpy(d["chain_x_T"]),
                         torch.from_numpy(d["chain_zs"]), cond[:2])
     assert rel_mse(x, torch.from_numpy(d["chain_final"])) < 1e-9
+
+
+def test_laion_oracle_matches_reference_at_64x64(golden_dir):
+    """BASELINE.json configs[4] resolution: the reference class is fully convolutional
+    (conditional_diffusion_laion.py:304-332) and so is the oracle; golden from the reference itself."""
+    d = np.load(os.path.join(golden_dir, "laion_B2_hw64.npz"))
+    sd = make_state_dict_laion(0)
+    x_t, t = torch.from_numpy(d["x_t"]), torch.from_numpy(d["t"])
+    noise, cond = torch.from_numpy(d["noise"]), torch.from_numpy(d["cond"])
+    assert x_t.shape == (2, 4, 64, 64)
+    for mode in ("train", "eval"):
+        p, b = R.split_state(sd)
+        with torch.no_grad():
+            eps = RL.unet_forward(p, b, x_t, t, cond, training=(mode == "train"))
+        assert rel_mse(eps, torch.from_numpy(d[f"eps_{mode}"])) < 1e-10, mode
+        if mode == "train":
+            for k, v in b.items():
+                if v.dtype != torch.int64:
+                    assert torch.allclose(v, torch.from_numpy(d["buf__" + k.replace(".", "__")]), rtol=1e-5, atol=1e-5), k
+    loss, eps, grads, _ = RL.train_step_grads(sd, x_t, t, noise, cond)
+    assert abs(loss.item() - float(d["loss_train"])) < 1e-5 * float(d["loss_train"])
+    for k, g in grads.items():
+        if is_pre_bn_bias(k):
+            continue
+        gn = float(d["gnorm__" + k.replace(".", "__")])
+        assert abs(g.double().norm().item() - gn) <= 1e-3 * gn, k
+    T = int(d["chain_T"])
+    x = RL.sample_chain(sd, R.Schedule(num_timesteps=T), torch.from_numpy(d["chain_x_T"]),
+                        torch.from_numpy(d["chain_zs"]), cond[:1])
+    assert rel_mse(x, torch.from_numpy(d["chain_final"])) < 1e-9

@@ -63,6 +63,9 @@ _SIGS = {
     "tdx_mse_loss": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_float, C.c_int64, _ptr]),
     "tdx_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, _ptr]),
+    "tdx_adam_clip_scratch_bytes": (C.c_size_t, []),
+    "tdx_adam_step_clip": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_int, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
     "tdx_pack_conv3x3": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_conv3x3_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -108,6 +111,14 @@ _SIGS = {
     "tdx_embedding_bwd": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, _ptr]),
     "tdx_unet_create": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int]),
     "tdx_unet_create_ex": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int]),
+    "tdx_unet_create_hw": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tdx_unet_set_precision": (C.c_int, [_ptr, C.c_int]),
+    "tdx_pack_conv3x3_bf16": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_conv3x3_bf16_stat_tile_rows": (C.c_int, []),
+    "tdx_conv3x3_fwd_bf16": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "tdx_conv3x3_wgrad_bf16": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _ptr, _ptr, _ptr]),
     "tdx_unet_destroy": (C.c_int, [_ptr]),
     "tdx_unet_workspace_bytes": (C.c_size_t, [_ptr, C.c_int, C.c_int]),
     "tdx_unet_forward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int,

@@ -1,0 +1,499 @@
+// bf16 compute mode of the 3x3 convolutions (opt-in; BASELINE.json configs[3]/[4] name bf16, the
+// reference itself is fp32-only - SURVEY.md 0): the same implicit GEMMs as conv3x3.hip on the
+// bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 rate), fp32 accumulation.
+//
+// What stays fp32: every tensor in HBM (activations, gradients, weight-gradient slabs, parameters),
+// the accumulators, the bias / BatchNorm-statistics epilogue, BatchNorm itself and the time MLP.
+// What becomes bf16: the two MFMA operands, rounded to nearest-even while the tile is staged
+// (activations: fp32 global load -> [BN+ReLU on load] -> v_cvt_pk_bf16_f32 -> LDS; weights: packed to
+// bf16 once per step).  That is autocast-like arithmetic with fp32 outputs; its tolerance is stated
+// in tests/test_gpu_bf16.py (eps_hat MSE <= 5e-4 against the fp32 goldens).
+//
+// At 16x the matrix rate these layers are HBM/L2-bound, not MFMA-bound: a K-tile is 64 channels of
+// one tap (4 MFMA k-steps), tiles are 128 pixels x 128|64 output channels, the BN+ReLU of the
+// producing layer is applied while staging (VALU is free here, so nothing is materialised), and the
+// nine taps of a tile re-read their rows from L1/L2.
+#include "conv_shared.h"
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define KT 64    // K-tile (bf16 elements): 64 channels of one tap / 64 pixels (wgrad)
+#define KTP 72   // padded LDS row: 144 B, conflict-free for the 16-lane groups of ds_read_b128
+
+// ---------------------------------------------------------------------------------- forward / dgrad
+template <int BM, int BN, bool IN_BN, int EPI>
+__global__ void __launch_bounds__(256)
+conv3x3_bf16_kernel(ConvArgs a) {
+  constexpr int WGN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 16;  // fp32 float4 loads per thread per K-tile (16 per 64-channel row)
+  constexpr int BI = BN / 32;  // 16-byte bf16 loads per thread per K-tile (8 per row)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [2][BM][KTP]
+  __bf16* Bs = As + 2 * BM * KTP;                    // [2][BN][KTP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  // XCD-aware tile ids, as in conv3x3_igemm_kernel: the column tiles of one row tile share an XCD
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W;
+
+  const int a_c4 = tid & 15, a_row = tid >> 4;  // A: 16 float4 per row, 16 rows per pass
+  const int b_ch = tid & 7, b_row = tid >> 3;   // B: 8 x 16 B per row, 32 rows per pass
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0,
+                                                        a.Cout * 9 * a.Cin * 2, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned a_off[AI], a_taps[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int p = m0 + a_row + 16 * i;
+    unsigned taps = 0;
+    if (p < a.M) {
+      const int r = p % HW, oh = r / a.W, ow = r % a.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) taps |= 1u << t;
+      }
+    }
+    a_taps[i] = taps;
+    a_off[i] = (unsigned)(p * a.Cin + a_c4 * 4) * 4u;
+  }
+  unsigned w_off[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) w_off[j] = (unsigned)((n0 + b_row + 32 * j) * 9 * a.Cin + b_ch * 8) * 2u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  const int nk = 9 * (a.Cin / KT);
+  f32x4 ra[AI], rb[BI];
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+
+  int cur = 1;
+  for (int kt = -1; kt < nk; ++kt) {
+    unsigned okmask = 0;
+    {
+      const int kn = min(kt + 1, nk - 1);
+      const int cblk = kn / 9, tap = kn - cblk * 9;
+      const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * 4u;
+      const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * KT) * 2u;
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
+      if (IN_BN) {
+        sc4 = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * 4);
+        sh4 = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = (a_taps[i] >> tap) & 1u;
+        if (IN_BN) okmask |= ok ? (1u << i) : 0u;
+        ra[i] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? a_off[i] : OOB, soff_in, 0));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt >= 0) {
+      const __bf16* Ab = As + cur * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
+      const __bf16* Bb = Bs + cur * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < KT / 16; ++ks) {
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + im * 32 * KTP + ks * 16);
+#pragma unroll
+        for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + in * 32 * KTP + ks * 16);
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      __bf16* Ab = As + (cur ^ 1) * BM * KTP;
+      __bf16* Bb = Bs + (cur ^ 1) * BN * KTP;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        f32x4 v = ra[i];
+        if (IN_BN) {
+          // padding must stay 0 AFTER the transform (relu(shift) != 0)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc4[e], sh4[e]), 0.f);
+          if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<bf16x4*>(Ab + (a_row + 16 * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
+      }
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        *reinterpret_cast<f32x4*>(Bb + (b_row + 32 * j) * KTP + b_ch * 8) = rb[j];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  conv_epilogue<BM, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw), tile_m, m0, n0, wm, wn, l31, half,
+                                    tid);
+}
+
+// --------------------------------------------------------------------------------------------- wgrad
+// dW[co][tap][ci] = sum_p dy[p][co] * in[p + tap][ci].  Both operands are pixel-major in memory while
+// the MFMA wants 8 consecutive k (pixels) of one row (channel) per lane, so the tiles are transposed
+// while they are staged: a thread loads 4 pixels x 4 channels (four float4), and writes, per channel,
+// the four pixels as one 8-byte bf16 pack into LDS[channel][pixel].  K-tile = 64 pixels.
+template <int BM, int BN, bool IN_BN>
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_bf16_kernel(WgradArgs a) {
+  constexpr int WGN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ACH = BM / 4, BCH = BN / 4;            // float4 columns per pixel row
+  constexpr int APG = 256 / ACH, BPG = 256 / BCH;      // 4-pixel groups handled per pass
+  constexpr int APASS = KT / (4 * APG), BPASS = KT / (4 * BPG);
+  static_assert(APASS >= 1 && BPASS >= 1, "tile too narrow for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [2][BM][KTP]  dy^T
+  __bf16* Bs = As + 2 * BM * KTP;                    // [2][BN][KTP]  in^T (shifted by the tap)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // (pixel chunk, co tile, ci tile, tap) from the workgroup id: the nine taps of a group share an XCD
+  const int L = blockIdx.x;
+  const int g = (L / 72) * 8 + (L % 8);
+  const int tap = (L % 72) / 8;
+  if (g >= a.groups) return;
+  const int tiles = a.tilesCo * a.tilesCi;
+  const int split = g / tiles, tl = g % tiles;
+  const int tile_co = tl / a.tilesCi, tile_ci = tl % a.tilesCi;
+  const int co0 = tile_co * BM, ci0 = tile_ci * BN;
+  const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+  const int HW = a.H * a.W;
+  const int p_lo = split * a.chunk;
+  const int p_hi = min(p_lo + a.chunk, a.M);
+  const int nk = (p_hi - p_lo + KT - 1) / KT;
+
+  const int a_c4 = tid % ACH, a_pg = tid / ACH;
+  const int b_c4 = tid % BCH, b_pg = tid / BCH;
+  constexpr unsigned OOB = 0x80000000u;
+  const int neg = (a.W + 1) * a.Cin;
+  // the dy descriptor ENDS at this workgroup's last pixel: the ragged end of the range reads zeros
+  const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0,
+                                                         (int)((int64_t)p_hi * a.Cout * 4), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * 4u;
+  unsigned a_off[APASS], b_off[BPASS];
+#pragma unroll
+  for (int q = 0; q < APASS; ++q) a_off[q] = (unsigned)((q * 4 * APG + a_pg * 4) * a.Cout + co0 + a_c4 * 4) * 4u;
+#pragma unroll
+  for (int q = 0; q < BPASS; ++q) b_off[q] = (unsigned)((q * 4 * BPG + b_pg * 4) * a.Cin + ci0 + b_c4 * 4) * 4u;
+  // (oh, ow) of the first pixel of each 4-pixel group this thread stages for B; advanced by KT pixels
+  // per K-tile (tiles are requested strictly in order)
+  int b_oh[BPASS], b_ow[BPASS];
+#pragma unroll
+  for (int q = 0; q < BPASS; ++q) {
+    const int r = (p_lo + q * 4 * BPG + b_pg * 4) % HW;
+    b_oh[q] = r / a.W;
+    b_ow[q] = r % a.W;
+  }
+  const int adv_q = KT / a.W, adv_s = KT % a.W;
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (IN_BN) {
+    sc4 = *reinterpret_cast<const f32x4*>(a.in_scale + ci0 + b_c4 * 4);
+    sh4 = *reinterpret_cast<const f32x4*>(a.in_shift + ci0 + b_c4 * 4);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  f32x4 ra[APASS][4], rb[BPASS][4];
+  unsigned okB = 0;  // bit (q*4 + e): pixel e of group q has its tap inside the image
+
+  auto load_tile = [&](int kt, bool advance) {
+    const int pbase = p_lo + kt * KT;
+    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 4u;
+    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 4u + tap_shift;
+#pragma unroll
+    for (int q = 0; q < APASS; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        ra[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rsrc_dy, a_off[q] + (unsigned)(e * a.Cout) * 4u, soff_a, 0));
+    okB = 0;
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      if (advance) {
+        int ow = b_ow[q] + adv_s, oh = b_oh[q] + adv_q;
+        if (ow >= a.W) { ow -= a.W; oh += 1; }
+        while (oh >= a.H) oh -= a.H;
+        b_ow[q] = ow;
+        b_oh[q] = oh;
+      }
+      int oh = b_oh[q], ow = b_ow[q];
+      const int pix0 = pbase + q * 4 * BPG + b_pg * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ih = oh + dh, iw = ow + dw;
+        // (pixels past the tensor are refused too: their dy rows are zero, but 0 * garbage may be NaN)
+        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && pix0 + e < a.M;
+        okB |= ok ? (1u << (q * 4 + e)) : 0u;
+        rb[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rsrc_in, ok ? b_off[q] + (unsigned)(e * a.Cin) * 4u : OOB, soff_b, 0));
+        if (++ow == a.W) { ow = 0; if (++oh == a.H) oh = 0; }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    __bf16* Ab = As + buf * BM * KTP;
+    __bf16* Bb = Bs + buf * BN * KTP;
+#pragma unroll
+    for (int q = 0; q < APASS; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 v = {ra[q][0][c], ra[q][1][c], ra[q][2][c], ra[q][3][c]};
+        *reinterpret_cast<bf16x4*>(Ab + (a_c4 * 4 + c) * KTP + q * 4 * APG + a_pg * 4) = __builtin_convertvector(v, bf16x4);
+      }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      f32x4 x[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = rb[q][e];
+        if (IN_BN) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[e][c] = fmaxf(fmaf(x[e][c], sc4[c], sh4[c]), 0.f);
+          if (!((okB >> (q * 4 + e)) & 1u)) x[e] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding stays 0 after the transform
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 v = {x[0][c], x[1][c], x[2][c], x[3][c]};
+        *reinterpret_cast<bf16x4*>(Bb + (b_c4 * 4 + c) * KTP + q * 4 * BPG + b_pg * 4) = __builtin_convertvector(v, bf16x4);
+      }
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0, false);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tile(kt + 1, true);
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* Ab = As + cur * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
+    const __bf16* Bb = Bs + cur * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + im * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + in * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wn * WTN + in * 32 + l31;
+        slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[im][in][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------ packing
+// OIHW fp32 -> bf16 forward pack [Cout][9][Cin] and dgrad pack [Cin][9 mirrored][Cout]; one launch for
+// all units of a network (TdxPackBatch, destinations reinterpreted as bf16)
+__global__ void pack_conv3x3_batch_bf16_kernel(TdxPackBatch b) {
+  int u = 0;
+  while (u + 1 < b.count && (int)blockIdx.x >= b.chunk_start[u + 1]) ++u;
+  const int64_t n = (int64_t)b.cout[u] * b.cin[u] * 9;
+  const int cin = b.cin[u], cin_real = b.cin_real[u], cout = b.cout[u];
+  const float* __restrict__ w = b.w[u];
+  __bf16* __restrict__ wf = reinterpret_cast<__bf16*>(b.wf[u]);
+  __bf16* __restrict__ wd = reinterpret_cast<__bf16*>(b.wd[u]);
+  const int64_t base = (int64_t)(blockIdx.x - b.chunk_start[u]) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i >= n) break;
+    const int ci = (int)(i % cin);
+    const int tap = (int)((i / cin) % 9);
+    const int co = (int)(i / ((int64_t)9 * cin));
+    const float v = ci < cin_real ? w[((size_t)co * cin_real + ci) * 9 + tap] : 0.f;
+    if (wf) wf[i] = (__bf16)v;
+    if (wd) wd[((size_t)ci * 9 + (8 - tap)) * cout + co] = (__bf16)v;
+  }
+}
+
+int tdx_pack_conv3x3_batch_bf16(TdxPackBatch* b, tdx_stream_t stream) {
+  if (!b || b->count <= 0 || b->count > TDX_PACK_MAX) return TDX_E_BADARG;
+  int chunks = 0;
+  for (int u = 0; u < b->count; ++u) {
+    if (!b->w[u] || (!b->wf[u] && !b->wd[u]) || b->cin_real[u] <= 0 || b->cin_real[u] > b->cin[u]) return TDX_E_BADARG;
+    b->chunk_start[u] = chunks;
+    chunks += cdiv((int64_t)b->cout[u] * b->cin[u] * 9, 1024);
+  }
+  pack_conv3x3_batch_bf16_kernel<<<chunks, 256, 0, to_stream(stream)>>>(*b);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_pack_conv3x3_bf16(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin,
+                                     tdx_stream_t stream) {
+  if (!w_oihw || cout <= 0 || cin <= 0) return TDX_E_BADARG;
+  TdxPackBatch b;
+  b.count = 1;
+  b.w[0] = w_oihw; b.wf[0] = static_cast<float*>(w_fwd_bf16); b.wd[0] = static_cast<float*>(w_dgrad_bf16);
+  b.cout[0] = cout; b.cin[0] = cin; b.cin_real[0] = cin;
+  return tdx_pack_conv3x3_batch_bf16(&b, stream);
+}
+
+// ----------------------------------------------------------------------------------------- dispatch
+extern "C" int tdx_conv3x3_bf16_stat_tile_rows(void) { return 128; }
+
+template <int BM, int BN>
+static int launch_bf16(const ConvArgs& a, int flags, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * KTP * sizeof(__bf16);
+  const int grid = (cdiv(a.M, BM) + 7) / 8 * 8 * a.tilesN;
+  const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+  const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS : EPI_PLAIN;
+#define TDX_LAUNCH_BF16(INBN, EPI_)                                                                  \
+  do {                                                                                               \
+    auto kern = conv3x3_bf16_kernel<BM, BN, INBN, EPI_>;                                             \
+    static bool attr_set = false;                                                                    \
+    if (lds > 65536 && !attr_set) {                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 256, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (in_bn) {
+    if (epi == EPI_BNRELU) TDX_LAUNCH_BF16(true, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH_BF16(true, EPI_STATS);
+    else TDX_LAUNCH_BF16(true, EPI_PLAIN);
+  } else {
+    if (epi == EPI_BNRELU) TDX_LAUNCH_BF16(false, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH_BF16(false, EPI_STATS);
+    else TDX_LAUNCH_BF16(false, EPI_PLAIN);
+  }
+#undef TDX_LAUNCH_BF16
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const float* bias, float* out,
+                                    int B, int H, int W, int cin, int cout, int flags,
+                                    const float* in_scale, const float* in_shift,
+                                    const float* out_scale, const float* out_shift,
+                                    float* stats_partial, tdx_stream_t stream) {
+  if (!in || !wpk_bf16 || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  if (cin % KT || cout % 64) return TDX_E_SHAPE;
+  if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_BNRELU) && (!out_scale || !out_shift)) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_STATS) && !stats_partial) return TDX_E_BADARG;
+  if ((flags & TDX_CONV_OUT_STATS) && (flags & TDX_CONV_OUT_BNRELU)) return TDX_E_BADARG;
+  if (!tdx_conv3x3_shape_ok(B, H, W, cin, cout)) return TDX_E_SHAPE;
+  ConvArgs a;
+  a.in = in; a.w = static_cast<const float*>(wpk_bf16); a.bias = bias; a.out = out;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
+  a.stats = stats_partial;
+  a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)((int64_t)B * H * W);
+  a.splits = 1; a.kt_per_split = 0; a.dbg = 0;
+  hipStream_t st = to_stream(stream);
+  // memory-bound: the widest column tile re-reads the input least often
+  if (cout % 128 == 0) { a.tilesN = cout / 128; return launch_bf16<128, 128>(a, flags, st); }
+  a.tilesN = cout / 64;
+  return launch_bf16<128, 64>(a, flags, st);
+}
+
+template <int BM, int BN>
+static int launch_wgrad_bf16(const WgradArgs& a, bool in_bn, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * KTP * sizeof(__bf16);
+  dim3 grid((unsigned)(((int64_t)a.groups + 7) / 8 * 72));
+#define TDX_LAUNCH_WG(INBN)                                                                          \
+  do {                                                                                               \
+    auto kern = conv3x3_wgrad_bf16_kernel<BM, BN, INBN>;                                             \
+    static bool attr_set = false;                                                                    \
+    if (lds > 65536 && !attr_set) {                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 256, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (in_bn) TDX_LAUNCH_WG(true);
+  else TDX_LAUNCH_WG(false);
+#undef TDX_LAUNCH_WG
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* dw_slabs, int B, int H,
+                                      int W, int cin, int cout, int flags, const float* in_scale,
+                                      const float* in_shift, tdx_stream_t stream) {
+  if (!in || !dy || !dw_slabs || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  if (cin % 64 || cout % 64) return TDX_E_SHAPE;
+  const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+  if (in_bn && (!in_scale || !in_shift)) return TDX_E_BADARG;
+  if (!tdx_conv3x3_shape_ok(B, H, W, cin, cout)) return TDX_E_SHAPE;
+  const int64_t M64 = (int64_t)B * H * W;
+  int bm, bn, splits, chunk;
+  tdx_wgrad_plan(M64, cin, cout, &bm, &bn, &splits, &chunk);  // same splits / slab layout as the fp32 path
+  WgradArgs a;
+  a.in = in; a.dy = dy; a.slabs = dw_slabs; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
+  a.tilesCi = cin / bn; a.tilesCo = cout / bm; a.chunk = chunk;
+  a.groups = a.tilesCi * a.tilesCo * splits;
+  a.adv_q = 0; a.adv_s = 0;
+  hipStream_t st = to_stream(stream);
+  if (bm == 128 && bn == 128) return launch_wgrad_bf16<128, 128>(a, in_bn, st);
+  if (bm == 128 && bn == 64) return launch_wgrad_bf16<128, 64>(a, in_bn, st);
+  if (bm == 64 && bn == 128) return launch_wgrad_bf16<64, 128>(a, in_bn, st);
+  return launch_wgrad_bf16<64, 64>(a, in_bn, st);
+}

@@ -37,6 +37,7 @@ struct TdxPackBatch {
   int count;
 };
 int tdx_pack_conv3x3_batch(TdxPackBatch* b, tdx_stream_t stream);
+int tdx_pack_conv3x3_batch_bf16(TdxPackBatch* b, tdx_stream_t stream);  // wf / wd hold bf16 (either may be null)
 // conv3x3 weight packs / gradient for an input tensor zero-padded from cin_real to cin channels
 int tdx_pack_conv3x3_pad(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout, int cin_real,
                          int cin, tdx_stream_t stream);

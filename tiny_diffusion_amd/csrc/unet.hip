@@ -60,6 +60,24 @@ const NetSpec SPECS[2] = {
 
 constexpr int N_STAGES = 15;
 
+// The table rows are the reference resolutions.  The LAION network is fully convolutional
+// (floor-mode pooling, exact 2x up-sampling, skips at equal resolution:
+// conditional_diffusion_laion.py:304-332), so any input side hw = 32 * k / 4 (a multiple of 8, >= 32)
+// runs through the same code: every resolution of the table scales by hw / 32.  The MNIST network
+// resizes to fixed sizes (7->8, 14->16, 28->32, 32->28: diffusion.py:135-159): 28 only.
+bool make_spec(int kind, int hw, NetSpec* out) {
+  NetSpec S = SPECS[kind];
+  if (hw <= 0 || hw == S.hw0) { *out = S; return true; }
+  if (kind != 1 || hw % 8 || hw < 32 || hw > 512) return false;
+  auto sc = [&](int v) { return (int)((int64_t)v * hw / 32); };
+  S.hw0 = S.out_hw = hw;
+  for (int i = 0; i < 4; ++i) S.enc_hw[i] = sc(S.enc_hw[i]);
+  for (int i = 0; i < 3; ++i) S.dec_hw[i] = sc(S.dec_hw[i]);
+  for (int i = 0; i < 13; ++i) S.units[i].hw = sc(S.units[i].hw);
+  *out = S;
+  return true;
+}
+
 
 inline size_t align64(size_t n) { return (n + 63) / 64 * 64; }
 
@@ -135,6 +153,7 @@ int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (Net
 
 struct tdx_unet {
   int max_batch, num_classes, kind;
+  NetSpec spec_own;        // the table row scaled to this plan's resolution
   const NetSpec* spec;
   float* wpack;            // device: per unit fwd pack then dgrad pack
   size_t wf_off[13], wd_off[13];
@@ -162,12 +181,18 @@ struct tdx_unet {
 };
 
 extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes) {
-  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2) return TDX_E_BADARG;
+  return tdx_unet_create_hw(out, max_batch, kind, num_classes, 0);
+}
+
+extern "C" int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int num_classes, int hw) {
+  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2 || hw < 0) return TDX_E_BADARG;
   if (kind == TDX_UNET_LAION && num_classes != 0) return TDX_E_BADARG;
   if (kind == TDX_UNET_LATENT_MLP && num_classes <= 0) return TDX_E_BADARG;
+  NetSpec spec_hw;
   if (kind != TDX_UNET_LATENT_MLP) {
+    if (!make_spec(kind, hw, &spec_hw)) return TDX_E_SHAPE;
     // every unit must be addressable at max_batch (32-bit buffer offsets: tdx_conv3x3_shape_ok)
-    const NetSpec& S = SPECS[kind];
+    const NetSpec& S = spec_hw;
     for (int i = 0; i < 13; ++i)
       if (!tdx_conv3x3_shape_ok(max_batch, S.units[i].hw, S.units[i].hw, S.units[i].cin, S.units[i].cout))
         return TDX_E_SHAPE;
@@ -177,7 +202,8 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
   u->max_batch = max_batch;
   u->num_classes = num_classes;
   u->kind = kind;
-  u->spec = kind == TDX_UNET_LATENT_MLP ? nullptr : &SPECS[kind];
+  if (kind != TDX_UNET_LATENT_MLP) u->spec_own = spec_hw;
+  u->spec = kind == TDX_UNET_LATENT_MLP ? nullptr : &u->spec_own;
   size_t o = 64, so = 0;
   if (u->spec) {
     for (int i = 0; i < 13; ++i) {

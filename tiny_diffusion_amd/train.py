@@ -145,6 +145,7 @@ class TrainStep:
         self._graph_key = None
         self._hyper = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._clip_scratch = None
 
     # ------------------------------------------------------------------ setup
     def _flatten(self):
@@ -264,11 +265,22 @@ class TrainStep:
                     self.reducer.launch(bi)
             cur.wait_stream(self.comm)
         gscale = self.reducer.finish()
-        if self.max_grad_norm is not None:
-            # the flat buffer holds every gradient: one norm, one scale (stays on the device)
-            total = torch.linalg.vector_norm(self.flat_grad) * gscale
-            self.flat_grad.mul_((self.max_grad_norm / (total + 1e-6)).clamp(max=1.0))
         self.step_count += 1
+        if self.max_grad_norm is not None:
+            # clip_grad_norm_ fused into the optimizer pass (conditional_diffusion_laion.py:469-472): the
+            # flat buffer holds every gradient, so one sum of squares gives the total norm, and the
+            # Adam kernel applies the clip coefficient on the fly
+            if self._clip_scratch is None:
+                self._clip_scratch = torch.empty(lib.tdx_adam_clip_scratch_bytes(), dtype=torch.uint8, device=dev)
+            check(lib.tdx_adam_step_clip(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
+                                         self.betas[1], self.eps, self.step_count, gscale, float(self.max_grad_norm),
+                                         None if hyper is None else hyper.data_ptr(), self._clip_scratch.data_ptr(),
+                                         st), "tdx_adam_step_clip")
+            m._buf_epoch += 1
+            if hyper is None and self.cosine_T_max is not None:
+                self.lr = cosine_annealing_lr(self.step_count, self.base_lr, self.cosine_T_max, self.cosine_eta_min)
+            return self.loss
         if hyper is not None:  # being captured: scalars come from device memory at replay time
             check(lib.tdx_adam_step_dev(self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
                                         self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_param.numel(),

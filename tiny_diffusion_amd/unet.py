@@ -119,12 +119,13 @@ def backward_stage_params(cond: bool, time_name: str = "time_embedding", init_na
 class _Plan:
     """One tdx_unet handle + workspace per (device, batch size)."""
 
-    def __init__(self, batch: int, num_classes: int, device: torch.device, kind: int = KIND_MNIST):
+    def __init__(self, batch: int, num_classes: int, device: torch.device, kind: int = KIND_MNIST, hw: int = 0):
         self.batch = batch
         self.device = device
+        self.hw = hw
         h = C.c_void_p()
         with torch.cuda.device(device):
-            check(lib.tdx_unet_create_ex(C.byref(h), batch, kind, num_classes), "tdx_unet_create_ex")
+            check(lib.tdx_unet_create_hw(C.byref(h), batch, kind, num_classes, hw), "tdx_unet_create_hw")
         self.handle = h
         self.ws_bytes = lib.tdx_unet_workspace_bytes(h, batch, MODE_TRAIN)
         if self.ws_bytes == 0:
@@ -284,13 +285,21 @@ class NoiseModelBase(nn.Module):
         d.update(dict(self.named_buffers()))
         return d
 
-    def _plan(self, batch: int, device: torch.device) -> _Plan:
-        key = (device.index if device.index is not None else torch.cuda.current_device(), batch)
+    def _plan(self, batch: int, device: torch.device, hw: int = 0) -> _Plan:
+        """One plan per (device, batch[, resolution]).  ``hw``: input side when it differs from the
+        reference's (LAION network only)."""
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        key = (dev, batch) if not hw else (dev, batch, hw)
         p = self._plans.get(key)
         if p is None:
-            p = _Plan(batch, self.num_classes, device, self._arch.kind)
+            p = _Plan(batch, self.num_classes, device, self._arch.kind, hw)
             self._plans[key] = p
         return p
+
+    def _input_hw(self, x) -> int:
+        """0 for the reference resolution, else the (square) side of x."""
+        shp = tuple(self._arch.in_shape)
+        return 0 if len(shp) != 3 or x.shape[-1] == shp[-1] else int(x.shape[-1])
 
     def _param_ptrs(self):
         d = self._named()
@@ -330,7 +339,10 @@ class NoiseModelBase(nn.Module):
                 "tiny_diffusion_amd runs on MI355X only: got a CPU tensor and there is no "
                 "CPU fallback (the CPU restatement lives in oracle/ and is test-only)")
         shp = tuple(self._arch.in_shape)
-        if x.dim() != 1 + len(shp) or tuple(x.shape[1:]) != shp:
+        if self._arch.kind == KIND_LAION and x.dim() == 4 and x.shape[1] == shp[0] and x.shape[2] == x.shape[3] \
+                and x.shape[2] % 8 == 0 and 32 <= x.shape[2] <= 512:
+            pass  # fully convolutional (conditional_diffusion_laion.py:304-332): (B,4,H,H), H a multiple of 8
+        elif x.dim() != 1 + len(shp) or tuple(x.shape[1:]) != shp:
             raise ValueError(f"x must be (B,{','.join(map(str, shp))}), got {tuple(x.shape)}")
         if t.shape != (x.shape[0],):
             raise ValueError("t must have shape (B,)")
@@ -354,7 +366,7 @@ class NoiseModelBase(nn.Module):
             if (self._mode() if mode is None else mode) == MODE_TRAIN:
                 raise ValueError("empty batch in train mode: BatchNorm statistics are undefined")
             return x.new_empty((0,) + tuple(self._arch.in_shape), dtype=torch.float32), None, MODE_INFER
-        plan = self._plan(B, x.device)
+        plan = self._plan(B, x.device, self._input_hw(x))
         mode = self._mode() if mode is None else mode
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()
@@ -362,7 +374,7 @@ class NoiseModelBase(nn.Module):
         t = t.contiguous().to(torch.int64)
         if y is not None:
             y = y.contiguous().float() if self._arch.kind == KIND_LAION else y.contiguous().to(torch.int64)
-        out = torch.empty((B,) + tuple(self._arch.in_shape), dtype=torch.float32, device=x.device)
+        out = torch.empty((B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream
         if mode == MODE_INFER:
             self._refresh_infer_pack(plan, pptr, ptens, bptr, btens, st)
@@ -390,7 +402,7 @@ class NoiseModelBase(nn.Module):
         """One reverse step of sample() in place on ``x`` (tdx_unet_eval_step): the step index is
         read from and decremented in device memory, so the call can sit in a HIP graph."""
         B = x.shape[0]
-        plan = self._plan(B, x.device)
+        plan = self._plan(B, x.device, self._input_hw(x))
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()
         st = torch.cuda.current_stream(x.device).cuda_stream

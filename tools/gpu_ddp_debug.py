@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Why does the 2-rank gradient test miss the single-GPU gate?  Same shard configuration as
-tests/test_gpu_ddp.py, ONE process, no collective: per-parameter error of (a) the module path and
-(b) TrainStep against the fp64 oracle with the GPU's pool routing."""
+"""Why does the configuration of tests/test_gpu_ddp.py miss the single-GPU gradient gate?  ONE process,
+no collective: eps_hat error, per-parameter gradient error against the fp64 oracle evaluated (a) with
+the GPU's pool routing only and (b) with the GPU's pool routing AND ReLU active sets."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,9 +9,8 @@ import torch
 import torch.nn.functional as F
 from oracle import ref_cpu as R
 from oracle.weights import make_state_dict
-from parity_helpers import gpu_pool_routing, grad_precision_failures
-from tiny_diffusion_amd.conditional_diffusion import ForwardProcess, NoiseModel
-from tiny_diffusion_amd.train import TrainStep
+from parity_helpers import gpu_pool_routing, gpu_relu_masks, grad_precision_failures, is_pre_bn_bias, rel_mse
+from tiny_diffusion_amd.conditional_diffusion import NoiseModel
 
 
 def shard(rank, B=8):
@@ -28,21 +27,19 @@ sd = make_state_dict(6, True)
 for rank in (0, 1):
     x0, noise, t, y = shard(rank, B)
     x_t = R.q_sample(R.Schedule(), x0, t, noise)
-    for path in ("module", "trainstep"):
-        m = NoiseModel(); m.load_state_dict(sd); m = m.cuda().train()
-        if path == "module":
-            eps = m(x_t.cuda(), t.cuda(), y.cuda())
-            F.mse_loss(eps, noise.cuda()).backward()
-            got = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
-        else:
-            ts = TrainStep(m, ForwardProcess(), lr=1e-3)
-            ts.step(x0.cuda(), y.cuda(), t=t.cuda(), noise=noise.cuda())
-            torch.cuda.synchronize()
-            got = {k: v.detach().cpu().clone() for k, v in ts.grad_views.items()}
-        cpu_args = (sd, x_t, t, noise, y)
-        pidx = gpu_pool_routing(m, B, cpu_args)
-        _, _, g32, _ = R.train_step_grads(*cpu_args, pool_idx=pidx)
-        _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, pool_idx=pidx)
+    m = NoiseModel(); m.load_state_dict(sd); m = m.cuda().train()
+    eps = m(x_t.cuda(), t.cuda(), y.cuda())
+    F.mse_loss(eps, noise.cuda()).backward()
+    got = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    cpu_args = (sd, x_t, t, noise, y)
+    pidx = gpu_pool_routing(m, B, cpu_args)
+    masks, flips = gpu_relu_masks(m, B, cpu_args, pool_idx=pidx)
+    print(f"shard {rank}: ReLU active-set differences GPU vs exact (all within 1e-5 of 0): {flips}", flush=True)
+    for label, kw in (("routing only", dict(pool_idx=pidx)), ("routing + relu masks", dict(pool_idx=pidx, relu_masks=masks))):
+        _, e32, g32, _ = R.train_step_grads(*cpu_args, **kw)
+        _, e64, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, **kw)
         bad = grad_precision_failures(got, g32, g64, True)
-        worst = sorted(((got[k].double() - g64[k]).norm().item() / max(g64[k].norm().item(), 1e-30), k) for k in g64)[-5:]
-        print(f"rank-shard {rank} path {path}: {len(bad)} over the gate; worst {worst}", flush=True)
+        errs = sorted(((got[k].double() - g64[k]).norm().item() / max(g64[k].norm().item(), 1e-30), k)
+                      for k in g64 if not is_pre_bn_bias(k))
+        print(f"shard {rank} [{label}]: eps rel MSE vs fp64 {rel_mse(eps.detach(), e64):.2e}; {len(bad)} params over "
+              f"the gate; median err {errs[len(errs)//2][0]:.2e}; worst {[(f'{e:.1e}', k) for e, k in errs[-4:]]}", flush=True)

@@ -52,11 +52,11 @@ def arm(name, l1_impl, input_copy, stage, destroy_while_running=True):
         g = torch.Generator(device="cuda").manual_seed(it)
         x = torch.randn(B, 1, 28, 28, device="cuda", generator=g)
         t = torch.randint(0, 1000, (B,), device="cuda", generator=g)
-        lib.tdx_tune_set(b"time_stage", 14)
+        lib.tdx_tune_set(b"time_stage_diag", 14)
         ref_m = fresh(); grads(ref_m, x, t); torch.cuda.synchronize()
         ref = {k: p.grad.clone() for k, p in ref_m.named_parameters()}
         del ref_m; gc.collect()
-        lib.tdx_tune_set(b"time_stage", stage)
+        lib.tdx_tune_set(b"time_stage_diag", stage)
         a = fresh(); grads(a, x, t); torch.cuda.synchronize()
         b = fresh()
         grads(b, x, t)
@@ -138,7 +138,7 @@ DUMP = dump_seen
 out = [arm("instrumented old kernel, stage 6", 2, 0, 6),
        arm("old-kernel+hipMemcpyAsync, stage 6", 1, 0, 6),
        ]
-lib.tdx_diag_set_buffer(None); lib.tdx_tune_set(b"time_stage", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
+lib.tdx_diag_set_buffer(None); lib.tdx_tune_set(b"time_stage_diag", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/stage6_diag.json", "w"), indent=1)
 print(json.dumps([{k: v for k, v in o.items() if k != "report"} for o in out]))

@@ -28,11 +28,11 @@ for it in range(iters):
     g = torch.Generator(device="cuda").manual_seed(it)
     x = torch.randn(B, 1, 28, 28, device="cuda", generator=g)
     t = torch.randint(0, 1000, (B,), device="cuda", generator=g)
-    lib.tdx_tune_set(b"time_stage", 14)
+    lib.tdx_tune_set(b"time_stage_diag", 14)
     ref_m = fresh(); grads(ref_m, x, t); torch.cuda.synchronize()
     ref = {k: p.grad.clone() for k, p in ref_m.named_parameters()}
     del ref_m; gc.collect()
-    lib.tdx_tune_set(b"time_stage", 6)
+    lib.tdx_tune_set(b"time_stage_diag", 6)
     a = fresh(); grads(a, x, t); torch.cuda.synchronize()
     b = fresh()
     grads(b, x, t)
@@ -42,6 +42,6 @@ for it in range(iters):
     bad += bool(wrong)
     print(f"iter {it}: {'ok' if not wrong else 'BAD ' + str(wrong)}", flush=True)
     del b; gc.collect()
-lib.tdx_tune_set(b"time_stage", 14)
+lib.tdx_tune_set(b"time_stage_diag", 14)
 print(f"done: {bad} bad of {iters}")
 sys.exit(1 if bad else 0)

@@ -312,6 +312,58 @@ def laion_fixtures(mod):
     print("laion_B8 loss train/eval", d["loss_train"], d["loss_eval"])
 
 
+def laion64_fixtures(mod):
+    """The same reference class at the resolution BASELINE.json configs[4] words (64x64): the
+    reference forward is fully convolutional (conditional_diffusion_laion.py:304-332), so
+    (4,64,64) latents run through it unchanged.  B = 2 keeps the file small."""
+    from oracle.weights import make_state_dict_laion
+
+    sd = make_state_dict_laion(0)
+    rs = np.random.RandomState(6464)
+    B, H = 2, 64
+    x0 = rs.standard_normal((B, 4, H, H)).astype(np.float32)
+    noise = rs.standard_normal((B, 4, H, H)).astype(np.float32)
+    t = np.array([999, 123], dtype=np.int64)
+    cond = rs.standard_normal((B, 768)).astype(np.float32)
+    fp = mod.ForwardProcess()
+    tt, nt, ct = torch.from_numpy(t), torch.from_numpy(noise), torch.from_numpy(cond)
+    x_t = (torch.sqrt(fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * torch.from_numpy(x0)
+           + torch.sqrt(1 - fp.alphas_cumprod[tt]).view(-1, 1, 1, 1) * nt)
+    d = dict(x_t=x_t.numpy(), noise=noise, t=t, cond=cond)
+    for mode in ("train", "eval"):
+        model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.train(mode == "train")
+        with torch.no_grad():
+            eps = model(x_t, tt, ct)
+        assert eps.shape == (B, 4, H, H)
+        d[f"eps_{mode}"] = eps.numpy()
+        d[f"loss_{mode}"] = np.float64(F.mse_loss(eps, nt).item())
+        if mode == "train":
+            d.update({"buf__" + k: v for k, v in bn_buffers(model).items()})
+    model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.train()
+    loss = F.mse_loss(model(x_t, tt, ct), nt); loss.backward()
+    for k, p in model.named_parameters():
+        g = p.grad.detach().contiguous().view(-1); kk = k.replace(".", "__")
+        d[f"gnorm__{kk}"] = np.float64(g.double().norm().item())
+        d[f"ghead__{kk}"] = g[:64].numpy().copy()
+    # reverse chain, T = 4, n = 1, recorded noise (conditional_diffusion_laion.py:574-587)
+    T, n = 4, 1
+    fpT = mod.ForwardProcess(num_timesteps=T)
+    model = mod.NoiseModel(); model.load_state_dict(sd, strict=True); model.eval()
+    g = torch.Generator().manual_seed(64)
+    x = torch.randn(n, 4, H, H, generator=g); x_T = x.clone()
+    zs = np.zeros((T, n, 4, H, H), np.float32)
+    with torch.no_grad():
+        for step in reversed(range(T)):
+            eps = model(x, torch.full((n,), step, dtype=torch.long), ct[:n])
+            z = torch.randn(x.shape, generator=g) if step > 0 else torch.zeros_like(x)
+            zs[step] = z.numpy()
+            alpha, ac, beta = fpT.alphas[step], fpT.alphas_cumprod[step], fpT.betas[step]
+            x = (1 / torch.sqrt(alpha)) * (x - ((1 - alpha) / torch.sqrt(1 - ac)) * eps) + torch.sqrt(beta) * z
+    d.update(chain_x_T=x_T.numpy(), chain_zs=zs, chain_final=x.numpy(), chain_T=T)
+    np.savez_compressed(os.path.join(OUT, "laion_B2_hw64.npz"), **d)
+    print("laion_B2_hw64 loss train/eval", d["loss_train"], d["loss_eval"])
+
+
 def load_reference_latent():
     """latent_diffusion.py imports vae.py, whose module body builds MNIST datasets
     (``download=True``), data loaders, a model, an optimizer and ``os.makedirs("checkpoints")``
@@ -488,10 +540,16 @@ def main():
     sample_fixture(unc, False, 20, 4, keep=[19, 10, 1, 0])
     sample_fixture(con, True, 20, 4, keep=[19, 10, 1, 0])
     sample_fixture(unc, False, 1000, 4, keep=[999, 750, 500, 250, 1, 0])
-    laion_fixtures(load_reference("conditional_diffusion_laion.py"))
+    lmod = load_reference("conditional_diffusion_laion.py")
+    laion_fixtures(lmod)
+    laion64_fixtures(lmod)
     latent_fixtures()
     transformer_fixtures()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-laion64":   # add the round-2 fixture, leave the others alone
+        os.makedirs(OUT, exist_ok=True)
+        laion64_fixtures(load_reference("conditional_diffusion_laion.py"))
+    else:
+        main()
