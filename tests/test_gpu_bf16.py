@@ -1,0 +1,251 @@
+"""GPU: the opt-in bf16 compute mode (BASELINE.json configs[3]/[4] name bf16; the reference itself is
+fp32-only, SURVEY.md 0, so there is no reference behaviour to match bit for bit).
+
+Arithmetic: the three 3x3-convolution GEMMs (forward, input gradient, weight gradient) run on
+v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (nearest even) and fp32 accumulation; tensors,
+BatchNorm statistics, BatchNorm, pooling / resizing, the time MLP, the loss and Adam stay fp32.
+
+Tolerances stated here:
+  * kernels: against the SAME arithmetic on the CPU (operands rounded to bf16, fp64 accumulation):
+    relative error <= 2e-5 (fp32 accumulation order only);
+  * whole network: eps_hat MSE <= 5e-4 against the fp32 vectors of the reference (SURVEY.md 8(c):
+    the reference under bf16 autocast is itself 5e-5 .. 1.5e-4 from fp64), loss within 2 %,
+    parameter gradients at cosine similarity >= 0.95 (worst: a BatchNorm bias twelve layers from the
+    loss at B = 8) and >= 0.99 (median; 0.992 at B = 2, 64x64) with the fp32 oracle's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle import ref_laion as RL  # noqa: E402
+from oracle.weights import make_state_dict, make_state_dict_laion  # noqa: E402
+from parity_helpers import is_pre_bn_bias  # noqa: E402
+
+EPS_MSE_TOL = 5e-4
+
+
+@pytest.fixture(scope="module")
+def tdx():
+    import tiny_diffusion_amd._lib as L
+
+    return L
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+BF16_CASES = [
+    # B, H, cin, cout: every tile template (128x128 / 128x64 forward; 128x128, 128x64, 64x128, 64x64 wgrad),
+    # ragged M, the LAION widths (192, 384) and a 64x64 map
+    (4, 28, 64, 128), (3, 14, 128, 256), (5, 7, 256, 512), (7, 4, 512, 512), (3, 8, 1024, 256),
+    (2, 16, 384, 128), (2, 32, 192, 64), (2, 32, 64, 64), (1, 64, 64, 64), (33, 8, 128, 128),
+]
+
+
+@pytest.mark.parametrize("B,H,cin,cout", BF16_CASES)
+def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
+    lib, check = tdx.lib, tdx.check
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(B, cout, H, H, generator=g)
+    # the same arithmetic on the host: bf16-rounded operands, exact products, fp64 sums
+    xr, wr, dyr = bf16_round(x), bf16_round(w), bf16_round(dy)
+    xr.requires_grad_(True); wr.requires_grad_(True)
+    ref = F.conv2d(xr, wr, b.double(), padding=1)
+    ref_dw, = torch.autograd.grad(ref, wr, dyr, retain_graph=True)   # weight gradient: dy and x rounded
+    ref_dx, = torch.autograd.grad(ref, xr, dyr)                      # input gradient: dy and w rounded
+
+    wd = w.cuda().contiguous()
+    wf16 = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device="cuda")
+    wg16 = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device="cuda")
+    check(lib.tdx_pack_conv3x3_bf16(wd.data_ptr(), wf16.data_ptr(), wg16.data_ptr(), cout, cin, st()))
+    assert torch.equal(wf16.view(cout, 9, cin).float().cpu(), w.permute(0, 2, 3, 1).reshape(cout, 9, cin).bfloat16().float())
+    xin = nhwc(x).cuda()
+    out = torch.full((B, H, H, cout), float("nan"), device="cuda")
+    M = B * H * H
+    rows = lib.tdx_conv3x3_bf16_stat_tile_rows()
+    tiles = -(-M // rows)
+    stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
+    bd = b.cuda()
+    check(lib.tdx_conv3x3_fwd_bf16(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin, cout,
+                                   4, None, None, None, None, stats.data_ptr(), st()))
+    torch.cuda.synchronize()
+    assert rel_err(nchw(out), ref.detach()) < 2e-5
+    flat = out.reshape(-1, cout).double().cpu()   # statistics of what was written
+    for ti in range(tiles):
+        blk = flat[ti * rows:(ti + 1) * rows]
+        assert torch.allclose(stats[ti, 0].double().cpu(), blk.sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(stats[ti, 1].double().cpu(), (blk - blk.mean(0)).pow(2).sum(0), rtol=1e-4, atol=1e-3)
+    # input gradient = the same kernel on dy with the mirrored pack, channel roles swapped
+    gd = nhwc(dy).cuda()
+    gin = torch.full((B, H, H, cin), float("nan"), device="cuda")
+    check(lib.tdx_conv3x3_fwd_bf16(gd.data_ptr(), wg16.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                   None, None, None, None, None, st()))
+    assert rel_err(nchw(gin), ref_dx) < 2e-5
+    splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    check(lib.tdx_conv3x3_wgrad_bf16(xin.data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 0, None, None,
+                                     st()))
+    check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st()))
+    assert rel_err(dw, ref_dw) < 2e-5
+
+
+def test_bf16_conv_bn_relu_on_load_and_fused_epilogue(tdx):
+    """BN+ReLU of the producing layer applied while staging (forward and weight gradient) and the
+    inference epilogue relu((acc + bias) * scale + shift)."""
+    lib, check = tdx.lib, tdx.check
+    B, H, cin, cout = 3, 14, 128, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    isc, ish = torch.randn(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    osc, osh = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.3
+    dy = torch.randn(B, cout, H, H, generator=g)
+    a = bf16_round(F.relu(torch.addcmul(ish.view(1, -1, 1, 1), x, isc.view(1, -1, 1, 1))))  # fp32 fma, then rounded
+    wr = bf16_round(w).requires_grad_(True)
+    conv = F.conv2d(a, wr, b.double(), padding=1)
+    ref = F.relu(conv * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1))
+    ref_dw, = torch.autograd.grad(conv, wr, bf16_round(dy))
+    wf16 = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device="cuda")
+    check(lib.tdx_pack_conv3x3_bf16(w.cuda().data_ptr(), wf16.data_ptr(), None, cout, cin, st()))
+    xin, iscd, ishd, oscd, oshd, bd = nhwc(x).cuda(), isc.cuda(), ish.cuda(), osc.cuda(), osh.cuda(), b.cuda()
+    out = torch.empty((B, H, H, cout), device="cuda")
+    check(lib.tdx_conv3x3_fwd_bf16(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin, cout,
+                                   1 | 2, iscd.data_ptr(), ishd.data_ptr(), oscd.data_ptr(), oshd.data_ptr(), None, st()))
+    assert rel_err(nchw(out), ref.detach()) < 3e-5
+    splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    slabs = torch.empty((splits, cout, 9, cin), device="cuda")
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    gd = nhwc(dy).cuda()
+    check(lib.tdx_conv3x3_wgrad_bf16(xin.data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 1,
+                                     iscd.data_ptr(), ishd.data_ptr(), st()))
+    check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st()))
+    assert rel_err(dw, ref_dw) < 3e-5
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1).cpu()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+
+
+def _check_against_fp32(m, args_gpu, noise, eps_ref, loss_ref, grads_ref, tag):
+    eps = m(*args_gpu)
+    loss = F.mse_loss(eps, noise.cuda())
+    loss.backward()
+    mse = ((eps.detach().cpu().double() - eps_ref.double()) ** 2).mean().item()
+    rel = mse / (eps_ref.double() ** 2).mean().item()
+    print(f"{tag}: bf16 eps_hat MSE vs fp32 reference {mse:.3e} (relative {rel:.3e}), loss {loss.item():.5f} vs {loss_ref:.5f}")
+    assert mse <= EPS_MSE_TOL, (tag, mse)
+    assert abs(loss.item() - loss_ref) <= 2e-2 * abs(loss_ref), (tag, loss.item(), loss_ref)
+    cos = []
+    for k, p in m.named_parameters():
+        if is_pre_bn_bias(k) or k not in grads_ref:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        cos.append((_cos(p.grad, grads_ref[k]), k))
+    cos.sort()
+    med = cos[len(cos) // 2][0]
+    print(f"{tag}: gradient cosine vs the fp32 oracle: worst {cos[:3]}, median {med:.5f}")
+    assert cos[0][0] >= 0.95 and med >= 0.99, (cos[:3], med)
+
+
+def test_bf16_mnist_unet_against_fp32_golden(golden_dir):
+    """configs[1] network in bf16 mode against the reference's fp32 vectors (B = 64, train-mode BN)."""
+    from tiny_diffusion_amd.diffusion import NoiseModel
+
+    d = np.load(os.path.join(golden_dir, "grad_B64_uncond.npz"))
+    sd = make_state_dict(int(d["seed"]), False)
+    m = NoiseModel(); m.load_state_dict(sd); m = m.cuda().train()
+    assert m.compute_dtype == torch.float32
+    m.set_compute_dtype(torch.bfloat16)
+    x_t, t, noise = torch.from_numpy(d["x_t"]), torch.from_numpy(d["t"]), torch.from_numpy(d["noise"])
+    _, _, g32, _ = R.train_step_grads(sd, x_t, t, noise)
+    _check_against_fp32(m, (x_t.cuda(), t.cuda()), noise, torch.from_numpy(d["eps_hat"]), float(d["loss"]), g32,
+                        "mnist B64")
+    # and back: the same module in fp32 mode reproduces the fp32 vectors exactly as before
+    m.set_compute_dtype(torch.float32)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        eps = m(x_t.cuda(), t.cuda())
+    assert ((eps.cpu().double() - torch.from_numpy(d["eps_hat"]).double()) ** 2).mean().item() < 1e-10
+
+
+@pytest.mark.parametrize("name,hw", [("laion_B8", 32), ("laion_B2_hw64", 64)])
+def test_bf16_laion_unet_against_fp32_golden(golden_dir, name, hw):
+    """configs[4] network (4 x hw x hw latents, hw = 32 and 64) in bf16 mode: train and eval forward,
+    gradients, and a graph-replayed reverse chain against the reference's fp32 vectors."""
+    from tiny_diffusion_amd.conditional_diffusion_laion import ForwardProcess, NoiseModel, sample
+
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = make_state_dict_laion(0)
+    x_t, t = torch.from_numpy(d["x_t"]), torch.from_numpy(d["t"])
+    cond, noise = torch.from_numpy(d["cond"]), torch.from_numpy(d["noise"])
+    assert x_t.shape[-1] == hw
+    m = NoiseModel(time_dim=768); m.load_state_dict(sd); m = m.cuda().train()
+    m.set_compute_dtype(torch.bfloat16)
+    _, _, g32, _ = RL.train_step_grads(sd, x_t, t, noise, cond)
+    _check_against_fp32(m, (x_t.cuda(), t.cuda(), cond.cuda()), noise, torch.from_numpy(d["eps_train"]),
+                        float(d["loss_train"]), g32, f"laion {hw}x{hw}")
+    m.load_state_dict(sd); m.eval()
+    with torch.no_grad():
+        eps = m(x_t.cuda(), t.cuda(), cond.cuda())
+    ref = torch.from_numpy(d["eps_eval"]).double()
+    rel = ((eps.cpu().double() - ref) ** 2).mean().item() / (ref ** 2).mean().item()
+    print(f"laion {hw}x{hw} eval: relative MSE {rel:.3e}")
+    assert rel <= 2e-4   # eval-mode outputs of this random-weight net are O(4): relative, not absolute
+    T = int(d["chain_T"])
+    n = d["chain_x_T"].shape[0]
+    x = sample(m, ForwardProcess(num_timesteps=T), "cuda", text_embeds=cond[:n], x_T=torch.from_numpy(d["chain_x_T"]),
+               noises=torch.from_numpy(d["chain_zs"]), use_graph=True)
+    fin = torch.from_numpy(d["chain_final"]).double()
+    relc = ((x.cpu().double() - fin) ** 2).mean().item() / (fin ** 2).mean().item()
+    print(f"laion {hw}x{hw} chain T={T}: relative MSE of x_0 {relc:.3e}")
+    assert torch.isfinite(x).all() and relc <= 1e-3
+
+
+def test_bf16_train_step_decreases_loss_like_fp32():
+    """A few optimisation steps (TrainStep: q_sample, forward, MSE, backward, Adam) in both modes from the
+    same initial weights and the same data: the loss curves stay within 3 % of each other."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
+    from tiny_diffusion_amd.train import TrainStep
+
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        m = NoiseModel().cuda().train().set_compute_dtype(dt)
+        ts = TrainStep(m, ForwardProcess(), lr=1e-3, philox_seed=5)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x0 = torch.rand(64, 1, 28, 28, device="cuda", generator=g) * 2 - 1
+        t = torch.randint(0, 1000, (64,), device="cuda", generator=g)
+        curves[dt] = [float(ts.step(x0, t=t)) for _ in range(8)]
+    a, b = curves[torch.float32], curves[torch.bfloat16]
+    print("fp32", [f"{v:.4f}" for v in a], "bf16", [f"{v:.4f}" for v in b])
+    assert b[-1] < b[0] and a[-1] < a[0]
+    assert all(abs(x - y) <= 0.03 * abs(x) for x, y in zip(a, b)), (a, b)

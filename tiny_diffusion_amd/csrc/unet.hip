@@ -160,6 +160,7 @@ struct tdx_unet {
   float* infer_ss;         // device: per unit scale|shift from running stats (INFER mode)
   size_t iss_off[13];
   bool packed;
+  int precision, saved_precision;  // TDX_PREC_*: of the next forward / of the saved forward
   int saved_batch, saved_mode;  // state of the last forward (for backward)
   // backward state that survives between tdx_unet_backward calls that split the stages:
   float* g_next;                // where the gradient w.r.t. the next unit's activation lives
@@ -221,6 +222,8 @@ extern "C" int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int n
   e = hipMalloc(&u->infer_ss, so * sizeof(float));
   if (e != hipSuccess) { (void)hipFree(u->wpack); delete u; return (int)e; }
   u->packed = false;
+  u->precision = TDX_PREC_F32;
+  u->saved_precision = TDX_PREC_F32;
   u->saved_batch = 0;
   u->saved_mode = -1;
   u->g_next = nullptr;
@@ -265,6 +268,14 @@ extern "C" int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int n
 
 extern "C" int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes) {
   return tdx_unet_create_ex(out, max_batch, 0, num_classes);
+}
+
+extern "C" int tdx_unet_set_precision(tdx_unet* u, int precision) {
+  if (!u || (precision != TDX_PREC_F32 && precision != TDX_PREC_BF16)) return TDX_E_BADARG;
+  if (!u->spec) return precision == TDX_PREC_F32 ? 0 : TDX_E_SHAPE;  // the latent MLP has no bf16 path
+  if (precision != u->precision) u->packed = false;                 // INFER packs are per precision
+  u->precision = precision;
+  return 0;
 }
 
 extern "C" int tdx_unet_destroy(tdx_unet* u) {
@@ -375,7 +386,11 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     pb.wd[i] = u->wpack + u->wd_off[i];
     pb.cout[i] = d.cout; pb.cin[i] = d.cin; pb.cin_real[i] = d.cin_real;
   }
-  if (overlap) {
+  if (u->precision == TDX_PREC_BF16) {
+    // bf16 packs live in the same slots (half the bytes); one launch, on the caller's stream
+    int rc = tdx_pack_conv3x3_batch_bf16(&pb, stream);
+    if (rc) return rc;
+  } else if (overlap) {
     // head now; the tail is launched by pack_tail() once the main stream has MFMA work in flight
     // (beside the tiny kernels at the start of a step it only slowed them down)
     TdxPackBatch head = pb;
@@ -471,7 +486,8 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const int64_t* labels = u->kind == 0 ? static_cast<const int64_t*>(cond) : nullptr;
   const float* cond_emb = u->kind == 1 ? static_cast<const float*>(cond) : nullptr;
 
-  if (!infer) RC(pack_impl(u, params, nullptr, stream, true));  // weights change every step
+  const bool bf16 = u->precision == TDX_PREC_BF16;
+  if (!infer) RC(pack_impl(u, params, nullptr, stream, !bf16));  // weights change every step
   else if (!u->packed) RC(pack_impl(u, params, buffers, stream));
   if (!infer) {
     // keep the inputs for backward (caller tensors may be gone by then)
@@ -501,6 +517,25 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const float* bias = P[TDX_P_UNIT0 + 4 * i + 1];
     float* Y = ws + L.Y[i];
     float* ss = ws + L.ss[i];
+    if (bf16) {
+      // bf16 operands, fp32 accumulate / storage; BN+ReLU of the producing unit applied while staging
+      // (nothing is materialised: the kernel is memory-bound and its VALU is idle)
+      const int64_t M = (int64_t)B * d.hw * d.hw;
+      if (infer) {
+        const float* iss = u->infer_ss + u->iss_off[i];
+        return tdx_conv3x3_fwd_bf16(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, nullptr,
+                                    nullptr, iss, iss + d.cout, nullptr, stream);
+      }
+      const int fl = (d.in_bn ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
+      RC(tdx_conv3x3_fwd_bf16(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, d.in_bn ? sc(i - 1) : nullptr,
+                              d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, stream));
+      const int rows = tdx_conv3x3_bf16_stat_tile_rows();
+      RC(tdx_bn_finalize(ws + L.stats, cdiv(M, rows), rows, M, d.cout, P[TDX_P_UNIT0 + 4 * i + 2],
+                         P[TDX_P_UNIT0 + 4 * i + 3], (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
+                         (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout, ss + 3 * d.cout,
+                         training ? 1 : 0, stream));
+      return 0;
+    }
     if (infer) {
       const float* iss = u->infer_ss + u->iss_off[i];
       // small-batch sampling is latency-bound: split K over more workgroups where the tile
@@ -529,10 +564,10 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
 
   // encoder: two units per level, then 2x2 max-pool of relu(bn(.))
   RC(run_unit(0, ws + L.x0));
-  if (!infer) RC(pack_tail(u, params, stream));  // beside unit 1's convolution
+  if (!infer && !bf16) RC(pack_tail(u, params, stream));  // beside unit 1's convolution
   for (int k = 0; k < 3; ++k) {
     const int ua = 2 * k, ub = 2 * k + 1;
-    if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
+    if (k == 1 && !infer && !bf16) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
     if (k > 0) RC(run_unit(ua, ws + L.ep[k - 1]));
     RC(run_unit(ub, ws + L.Y[ua]));
     if (!infer) {
@@ -579,6 +614,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
 
   u->saved_batch = infer ? 0 : B;
   u->saved_mode = mode;
+  u->saved_precision = u->precision;
   return 0;
 }
 
@@ -606,6 +642,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   u->side2 = u->use_streams ? u->side2_own : st;
   const int B = batch;
   const int training = u->saved_mode == TDX_MODE_TRAIN ? 1 : 0;
+  if (u->precision != u->saved_precision) return TDX_E_STATE;  // backward in the precision of its forward
+  const bool bf16 = u->saved_precision == TDX_PREC_BF16;
   // Activation gradients rotate through FOUR buffers, handed out least-recently-used: the weight
   // gradient of unit u (side stream) keeps reading dy(u) while the main stream is already two
   // units further down, so the two streams are coupled loosely - the side stream works through
@@ -661,8 +699,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                        stream));
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
     // NetSpec says overlap = 0).
-    const bool bn_on_load = d.in_bn && !u->materialize;
-    if (d.in_bn && u->materialize) in = ws + L.A[i - 1];  // materialised relu(bn(Y[i-1]))
+    const bool bn_on_load = d.in_bn && (!u->materialize || bf16);
+    if (d.in_bn && u->materialize && !bf16) in = ws + L.A[i - 1];  // materialised relu(bn(Y[i-1]))
     const float* isc = bn_on_load ? ws + L.ss[i - 1] : nullptr;
     const float* ish = bn_on_load ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
     const bool fork = true;
@@ -678,8 +716,12 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       TDX_HIP(hipStreamWaitEvent(wst, u->ev_red[i + 2], 0));
       u->red_pending[i + 2] = false;
     }
-    RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc, ish,
-                         reinterpret_cast<tdx_stream_t>(wst)));
+    if (bf16)
+      RC(tdx_conv3x3_wgrad_bf16(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc,
+                                ish, reinterpret_cast<tdx_stream_t>(wst)));
+    else
+      RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc, ish,
+                           reinterpret_cast<tdx_stream_t>(wst)));
     // dy is free again once the wgrad GEMM has read it
     TDX_HIP(hipEventRecord(u->ev_w[i], wst));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_w[i], 0));
@@ -694,8 +736,12 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     // main: input gradient = the forward kernel on the flipped pack, channels swapped
     float* g_in;
     RC(acquire(g, nullptr, &g_in));
-    RC(tdx_conv3x3_fwd(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+    if (bf16)
+      RC(tdx_conv3x3_fwd_bf16(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, stream));
+    else
+      RC(tdx_conv3x3_fwd(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, stream));
     *g_in_out = g_in;
     return 0;
   };

@@ -133,6 +133,7 @@ class _Plan:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         self.generation = 0      # bumped by every forward that saves state
         self.infer_key = None    # parameter versions the INFER pack was built from
+        self.precision = 0       # TDX_PREC_* the handle is set to
 
     def tensor(self, name: str) -> torch.Tensor:
         """View of a named intermediate inside the workspace (tests / debugging)."""
@@ -236,6 +237,7 @@ class NoiseModelBase(nn.Module):
         self._grad_flat = None
         self._grad_views = None
         self._buf_epoch = 0
+        self._precision = 0   # TDX_PREC_F32
         self._live_ctx = weakref.WeakSet()   # autograd nodes of this module whose backward has not run yet
 
     def _init_latent(self, arch, time_dim):
@@ -278,6 +280,30 @@ class NoiseModelBase(nn.Module):
         if arch.kind == KIND_LAION:  # registered after the projections in the reference
             self.pool = nn.MaxPool2d(2)
             self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+
+    # ---------------------------------------------------------------- precision
+    def set_compute_dtype(self, dtype) -> "NoiseModelBase":
+        """Arithmetic of the 3x3 convolutions (not in the reference, which is fp32-only; BASELINE.json
+        configs[3]/[4] name bf16): ``torch.float32`` (default, exact fp32 MFMA) or ``torch.bfloat16``
+        (bf16 MFMA operands, fp32 accumulation; parameters, activations, gradients, BatchNorm and the
+        time MLP stay fp32).  Applies to forwards issued afterwards; tolerance in tests/test_gpu_bf16.py."""
+        name = {torch.float32: 0, torch.bfloat16: 1, "fp32": 0, "f32": 0, "bf16": 1}.get(dtype)
+        if name is None:
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        if name == 1 and self._arch.kind == KIND_LATENT:
+            raise ValueError("the latent MLP has no bf16 path (2.8 MFLOP/sample, launch-bound)")
+        self._precision = name
+        return self
+
+    @property
+    def compute_dtype(self):
+        return torch.bfloat16 if self._precision == 1 else torch.float32
+
+    def _apply_precision(self, plan):
+        if plan.precision != self._precision:
+            check(lib.tdx_unet_set_precision(plan.handle, self._precision), "tdx_unet_set_precision")
+            plan.precision = self._precision
+            plan.infer_key = None
 
     # ---------------------------------------------------------------- plumbing
     def _named(self):
@@ -367,6 +393,7 @@ class NoiseModelBase(nn.Module):
                 raise ValueError("empty batch in train mode: BatchNorm statistics are undefined")
             return x.new_empty((0,) + tuple(self._arch.in_shape), dtype=torch.float32), None, MODE_INFER
         plan = self._plan(B, x.device, self._input_hw(x))
+        self._apply_precision(plan)
         mode = self._mode() if mode is None else mode
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()
@@ -403,6 +430,7 @@ class NoiseModelBase(nn.Module):
         read from and decremented in device memory, so the call can sit in a HIP graph."""
         B = x.shape[0]
         plan = self._plan(B, x.device, self._input_hw(x))
+        self._apply_precision(plan)
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()
         st = torch.cuda.current_stream(x.device).cuda_stream

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""In-situ figures of the training step from a rocprofv3 kernel trace of
+`python3 bench.py --train-only` (the real step: three streams, kernels sharing CUs):
+
+    python tools/insitu.py <..._kernel_trace.csv> profiles/r02_insitu.json
+
+Per step (delimited by the Adam kernel; the first two and the last step are dropped): wall time, the sum
+of the MFMA convolution kernels' durations (what `roofline.achieved` would be divided by if the
+launches were priced as they run inside the step, overlapping each other), the time covered by at
+least one convolution kernel, and the time with none in flight.  bench.py reports the file as
+`roofline.in_situ` beside the isolated-launch figure."""
+import csv
+import json
+import statistics
+import sys
+
+GFLOP_PER_STEP = 1726.8   # 13 units x {fwd, dgrad, wgrad} at B = 256 (bench.py: algorithmic_gflop_per_step)
+PEAK = 157.3
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel") or "adam_clip_kernel" in r["Kernel_Name"]]
+
+
+def isconv(n):
+    return "conv3x3_igemm" in n or "conv3x3_wgrad" in n or "conv3x3_bf16" in n
+
+
+steps = []
+for a, b in zip(adam[2:-1], adam[3:]):
+    seg = rows[a + 1:b + 1]
+    t0, t1 = int(rows[a]["End_Timestamp"]), int(seg[-1]["End_Timestamp"])
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg if isconv(r["Kernel_Name"]))
+    cov, (cs, ce) = 0, iv[0]
+    for s, e in iv[1:]:
+        if s > ce:
+            cov += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    cov += ce - cs
+    steps.append({"wall_ms": (t1 - t0) / 1e6, "conv_sum_ms": sum(e - s for s, e in iv) / 1e6, "conv_launches": len(iv),
+                  "conv_covered_ms": cov / 1e6, "no_conv_in_flight_ms": (t1 - t0 - cov) / 1e6,
+                  "kernels": len(seg)})
+med = {k: round(statistics.median(s[k] for s in steps), 3) for k in steps[0]}
+out = {"source": sys.argv[1].split("/")[-1], "steps_used": len(steps), "median_per_step": med,
+       "in_situ_tflops": round(GFLOP_PER_STEP / med["conv_sum_ms"], 1),
+       "in_situ_frac_of_157.3": round(GFLOP_PER_STEP / med["conv_sum_ms"] / PEAK, 4),
+       "covered_tflops": round(GFLOP_PER_STEP / med["conv_covered_ms"], 1),
+       "covered_frac_of_157.3": round(GFLOP_PER_STEP / med["conv_covered_ms"] / PEAK, 4),
+       "note": "in_situ = algorithmic conv GFLOP / sum of conv kernel durations inside the step (kernels overlap, so the "
+               "sum exceeds the wall time they occupy); covered = the same GFLOP / time with at least one conv kernel in flight"}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out))
