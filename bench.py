@@ -408,22 +408,27 @@ _LAION_CONVS = [(4, 32, 32), (32, 64, 32), (64, 64, 32), (64, 128, 16), (128, 12
 LAION_FWD_FLOP = sum(2 * 9 * ci * co * hw * hw for ci, co, hw in _LAION_CONVS)
 
 
-def laion_extras(steps: int = 40, warmup: int = 8):
-    """SURVEY.md 8(f) f3 (BASELINE.json configs[4] shape): training step of the LAION-shaped
-    latent UNet (q_sample + fwd + MSE + bwd + clip_grad_norm(10) + Adam, cosine LR) at the
-    reference's batch 8 and at 256, and the 1000-step reverse chain for its 4 prompts."""
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md (dense bf16 matrix; the sparse figure is 2x)
+
+
+def laion_extras(steps: int = 30, warmup: int = 6):
+    """SURVEY.md 8(f) f3 (BASELINE.json configs[4] shape): training step of the LAION-shaped latent UNet
+    (q_sample + fwd + MSE + bwd + clip_grad_norm(10) fused into Adam, cosine LR) at the reference's
+    batch 8 and at 256, on (4,32,32) latents (the reference's shape) and (4,64,64) (the config's
+    wording), in fp32 and in the opt-in bf16 compute mode (bf16 MFMA operands, fp32 accumulation and
+    storage - never the headline; tolerance in tests/test_gpu_bf16.py), and the 1000-step reverse chain
+    for 4 prompts."""
     from tiny_diffusion_amd.conditional_diffusion_laion import ForwardProcess, NoiseModel, sample
     from tiny_diffusion_amd.train import TrainStep
 
-    out = {"fwd_gflop_per_sample": round(LAION_FWD_FLOP / 1e9, 3)}
+    out = {"fwd_gflop_per_sample": round(LAION_FWD_FLOP / 1e9, 3), "fwd_gflop_per_sample_hw64": round(4 * LAION_FWD_FLOP / 1e9, 3)}
     fp = ForwardProcess()
-    for B, graph in ((8, False), (256, False)):
+
+    def leg(B, hw, dtype):
         torch.manual_seed(0)
-        model = NoiseModel(time_dim=768).cuda().train()
-        # graph: the whole step replayed as one HIP graph (the reference's batch size is launch-bound)
-        ts = TrainStep(model, fp, lr=1e-4, philox_seed=None if graph else 99, max_grad_norm=10.0,
-                       cosine_T_max=1000, cosine_eta_min=1e-6, use_graph=graph)
-        x0 = torch.randn(B, 4, 32, 32, device="cuda") * 0.8
+        model = NoiseModel(time_dim=768).cuda().train().set_compute_dtype(dtype)
+        ts = TrainStep(model, fp, lr=1e-4, philox_seed=99, max_grad_norm=10.0, cosine_T_max=1000, cosine_eta_min=1e-6)
+        x0 = torch.randn(B, 4, hw, hw, device="cuda") * 0.8
         cond = torch.randn(B, 768, device="cuda")
         for _ in range(warmup):
             ts.step(x0, cond)
@@ -435,20 +440,62 @@ def laion_extras(steps: int = 40, warmup: int = 8):
         dt = time.perf_counter() - t0
         lv = loss.item()
         if not (lv == lv) or lv > 1e3:
-            raise SystemExit(f"LAION training diverged in the benchmark: loss {lv}")
-        out[f"train_B{B}" + ("_graph" if graph else "")] = {
-            "samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-            "tflops": round(B * steps / dt * 3 * LAION_FWD_FLOP / 1e12, 2)}
-        if B == 8 and not graph:
-            model.eval()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            x = sample(model, fp, "cuda", text_embeds=cond[:4], use_graph=True, philox_seed=7)
-            torch.cuda.synchronize()
-            assert torch.isfinite(x).all()
-            out["sample_n4_s_per_1000_steps"] = round(time.perf_counter() - t0, 3)
-        del ts, model
+            raise SystemExit(f"LAION training diverged in the benchmark (B={B}, hw={hw}, {dtype}): loss {lv}")
+        flop = 3 * LAION_FWD_FLOP * (hw / 32) ** 2
+        res = {"samples_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+               "tflops": round(B * steps / dt * flop / 1e12, 2), "loss_after": round(lv, 4)}
+        return res, model, cond
+
+    r, model, cond = leg(8, 32, torch.float32)
+    out["train_B8"] = r
+    model.eval()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = sample(model, fp, "cuda", text_embeds=cond[:4], use_graph=True, philox_seed=7)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+    out["sample_n4_s_per_1000_steps"] = round(time.perf_counter() - t0, 3)
+    del model
+    out["train_B256"], _, _ = leg(256, 32, torch.float32)
+    out["train_B256_hw64"], _, _ = leg(256, 64, torch.float32)
+    bf = {"arithmetic": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation; fp32 tensors, BatchNorm, "
+                        "time MLP, loss, Adam", "peak_tflops": PEAK_BF16_MFMA_TFLOPS}
+    for key, B, hw in (("train_B256", 256, 32), ("train_B256_hw64", 256, 64)):
+        r, _, _ = leg(B, hw, torch.bfloat16)
+        r["frac_of_bf16_mfma_peak"] = round(r["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
+        r["speedup_vs_fp32"] = round(out[key]["ms_per_step"] / r["ms_per_step"], 2)
+        bf[key] = r
+    out["bf16"] = bf
+    torch.cuda.empty_cache()
     return out
+
+
+def mnist_bf16_leg(fp, steps: int = 30, warmup: int = 6):
+    """The headline workload in the opt-in bf16 compute mode (same step, same batch): reported beside
+    the fp32 value, never in its place."""
+    from tiny_diffusion_amd.diffusion import NoiseModel
+    from tiny_diffusion_amd.train import TrainStep
+
+    torch.manual_seed(0)
+    m = NoiseModel().cuda().train().set_compute_dtype(torch.bfloat16)
+    ts = TrainStep(m, fp, lr=1e-3, philox_seed=1234)
+    x0 = torch.rand(PER_GPU_BATCH, 1, 28, 28, device="cuda") * 2 - 1
+    for _ in range(warmup):
+        ts.step(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts.step(x0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lv = loss.item()
+    if not (lv == lv) or lv > 1e3:
+        raise SystemExit(f"bf16 training diverged in the benchmark: loss {lv}")
+    v = PER_GPU_BATCH * steps / dt
+    return {"images_per_s": round(v, 1), "ms_per_step": round(dt / steps * 1e3, 3), "loss_after": round(lv, 4),
+            "tflops": round(v * TRAIN_FLOP_PER_IMAGE / 1e12, 1),
+            "frac_of_bf16_mfma_peak": round(v * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "arithmetic": "bf16 MFMA operands, fp32 accumulation and storage (tests/test_gpu_bf16.py)"}
 
 
 def latent_extras(steps: int = 200, warmup: int = 20):
@@ -643,6 +690,8 @@ def main():
                              "n16_tflops": round(16 * 1000 * fwd / s16 / 1e12, 1),
                              "n64_tflops": round(64 * 1000 * fwd / s64 / 1e12, 1),
                              "cpu_n64_extrapolated_s": res["cpu_baseline"]["sample_chain_s_n64_extrapolated"]}
+            note("MNIST UNet in bf16 compute mode (opt-in, separate leg) ...")
+            res["bf16_mode"] = mnist_bf16_leg(fp)
             note("LAION leg ...")
             res["laion_unet"] = laion_extras()
             note("latent MLP leg ...")

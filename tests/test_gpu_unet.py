@@ -436,7 +436,7 @@ def test_benchmarked_batch_256_against_oracle(cond):
     BatchNorm; and the class-conditional model of configs[2] at the same per-GPU batch) against the
     CPU oracle: eps_hat, loss, EVERY gradient element, the BatchNorm buffers, and one TrainStep step
     (diffusion.py:225-236).  At this size pick_tile / pick_wgrad choose the 128x128 / 128x64 tiles,
-    224-way pixel splits and 896-pixel chunks no smaller test reaches."""
+    112- and 224-way pixel splits (1792- / 896-pixel chunks) no smaller test reaches."""
     from tiny_diffusion_amd._lib import lib
     from tiny_diffusion_amd.diffusion import ForwardProcess
     from tiny_diffusion_amd.train import TrainStep
@@ -445,7 +445,7 @@ def test_benchmarked_batch_256_against_oracle(cond):
     # this test is only worth its CPU time if it runs the launch geometries of the benchmark
     assert lib.tdx_conv3x3_tile_shape(B, 8, 8, 1024, 256, 0) == 128128
     assert lib.tdx_conv3x3_tile_shape(B, 32, 32, 256, 64, 0) == 128064
-    assert lib.tdx_conv3x3_wgrad_splits(B, 28, 28, 128, 128) == 224
+    assert lib.tdx_conv3x3_wgrad_splits(B, 28, 28, 128, 128) == 112 and lib.tdx_conv3x3_wgrad_splits(B, 28, 28, 64, 128) == 224
     sd = make_state_dict(7, cond)
     g = torch.Generator().manual_seed(256 + int(cond))
     x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1

@@ -567,6 +567,8 @@ static int g_splitk_tiles = 260;      // split K when the 64x64 grid has fewer t
                                       // MI355X: 192 -> 260 is neutral at n=16 and 4 % faster at n=64)
 static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
+static int g_wgrad_target_big = 1024; // the same for 128x128 tiles (0: g_wgrad_target): at most two of them fit a
+                                      // CU (64 KiB of LDS each), so fewer, longer workgroups halve the slab traffic
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
@@ -596,6 +598,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
+  if (!strcmp(key, "wgrad_target_big")) { g_wgrad_target_big = value > 0 ? value : 0; return 0; }
   return TDX_E_BADARG;
 }
 
@@ -1180,7 +1183,8 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
   // reduce (140 MB per layer).  64x64 tiles give 4x the workgroups from the weights alone.
   if (g_wgrad_small && (int64_t)cout * cin >= (1 << 17) && M <= 16384) { c.bm = 64; c.bn = 64; }
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
-  int64_t s = (g_wgrad_target + tiles - 1) / tiles;
+  const int target = (c.bm == 128 && c.bn == 128 && g_wgrad_target_big > 0) ? g_wgrad_target_big : g_wgrad_target;
+  int64_t s = (target + tiles - 1) / tiles;
   int64_t smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
