@@ -344,6 +344,11 @@ int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int num_classes)
  * multiple of 8 from 32 to 512 is accepted (64 = BASELINE.json configs[4]); the MNIST network resizes
  * to fixed sizes and takes 28 only.  TDX_E_SHAPE otherwise. */
 int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int num_classes, int hw);
+/* ... and an explicit width of the time embedding (the reference's NoiseModel(time_dim=...) constructor
+ * argument: diffusion.py:16, conditional_diffusion.py:19, conditional_diffusion_laion.py:236): 0 = the
+ * kind's default (256 / 768), else a multiple of 256 up to 1024 (the text embeddings of kind 1 have that
+ * width too).  TDX_E_SHAPE otherwise. */
+int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int num_classes, int hw, int time_dim);
 /* Arithmetic of the plan's 3x3 convolutions: TDX_PREC_F32 (default: exact fp32 MFMA) or TDX_PREC_BF16
  * (bf16 operands, fp32 accumulation and storage; see the bf16 section above).  Call before a forward;
  * a backward must run in the precision of its forward (TDX_E_STATE otherwise).  Not for kind 2. */

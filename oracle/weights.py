@@ -70,7 +70,7 @@ def key_shapes(cond: bool, num_classes: int = 10, time_dim: int = TIME_DIM):
     return out
 
 
-def make_state_dict(seed: int = 0, cond: bool = False, time_scale: float = 1.0):
+def make_state_dict(seed: int = 0, cond: bool = False, time_scale: float = 1.0, time_dim: int = TIME_DIM):
     """Reference-format state_dict (OIHW conv weights, fp32, int64 counters).
 
     ``time_scale`` multiplies ``time_embedding.0.weight`` only; 1.0 reproduces
@@ -78,7 +78,7 @@ def make_state_dict(seed: int = 0, cond: bool = False, time_scale: float = 1.0):
     """
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for key, shape, kind in key_shapes(cond):
+    for key, shape, kind in key_shapes(cond, time_dim=time_dim):
         if kind in ("conv_w", "lin_w"):
             fan_in = int(np.prod(shape[1:]))
             a = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
@@ -170,12 +170,12 @@ def key_shapes_laion(time_dim: int = LAION_TIME_DIM):
     return out
 
 
-def make_state_dict_laion(seed: int = 0):
+def make_state_dict_laion(seed: int = 0, time_dim: int = LAION_TIME_DIM):
     """Seeded reference-format state_dict of the LAION NoiseModel (same recipe as
     make_state_dict: portable numpy legacy RNG, non-trivial BN statistics)."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for key, shape, kind in key_shapes_laion():
+    for key, shape, kind in key_shapes_laion(time_dim):
         if kind in ("conv_w", "lin_w"):
             fan_in = int(np.prod(shape[1:]))
             a = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)

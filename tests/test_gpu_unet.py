@@ -510,3 +510,43 @@ def test_two_forwards_in_one_graph_accumulate():
         assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-9), k
     with pytest.raises(Exception):
         m(xa.clone().requires_grad_(True), ta)
+
+
+@pytest.mark.parametrize("time_dim", [512, 1024])
+def test_time_dim_constructor_argument(time_dim):
+    """NoiseModel(time_dim=...) (diffusion.py:16, conditional_diffusion.py:19: any width in the reference;
+    here multiples of 256 up to 1024): eps_hat and every gradient of the class-conditional model against
+    the oracle at a non-default width; other widths are refused with a ValueError."""
+    from tiny_diffusion_amd.conditional_diffusion import NoiseModel
+
+    sd = make_state_dict(8, True, time_dim=time_dim)
+    m = NoiseModel(time_dim=time_dim)
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in sd.values()]
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    B = 6
+    g = torch.Generator().manual_seed(time_dim)
+    x = torch.randn(B, 1, 28, 28, generator=g)
+    noise = torch.randn(B, 1, 28, 28, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g); t[0] = 999
+    y = torch.randint(0, 10, (B,), generator=g)
+    for training in (True, False):
+        m.load_state_dict(sd); m.train(training); m.zero_grad(set_to_none=True)
+        eps = m(x.cuda(), t.cuda(), y.cuda())
+        loss = F.mse_loss(eps, noise.cuda())
+        loss.backward()
+        cpu_args = (sd, x, t, noise, y)
+        pidx = _gpu_pool_routing(m, B, cpu_args, training)
+        loss_ref, eps_ref, g32, _ = R.train_step_grads(*cpu_args, training=training, pool_idx=pidx)
+        _, _, g64, _ = R.train_step_grads(*cpu_args, training=training, dtype=torch.float64, pool_idx=pidx)
+        assert rel_mse(eps.detach(), eps_ref) < REL_MSE_TOL
+        assert abs(loss.item() - loss_ref.item()) < 2e-5 * loss_ref.item()
+        bad = _grad_precision_failures({k: p.grad for k, p in m.named_parameters()}, g32, g64, training)
+        assert not bad, (time_dim, training, bad)
+    with torch.no_grad():   # fused inference path (sampling) at this width
+        m.eval()
+        p, b = R.split_state(sd)
+        assert rel_mse(m(x.cuda(), t.cuda(), y.cuda()), R.unet_forward(p, b, x, t, y, training=False)) < REL_MSE_TOL
+    for bad_dim in (100, 384, 2048):
+        with pytest.raises(ValueError):
+            NoiseModel(time_dim=bad_dim)

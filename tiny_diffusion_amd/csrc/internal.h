@@ -23,11 +23,11 @@ int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, fl
 // kind 0: raw-t MLP (+ class embedding y); kind 1: sinusoid + 768-d MLP + additive `cond`
 int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float* cond,
                        const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
-                       float* t3, int B, hipStream_t st);
+                       float* t3, int B, hipStream_t st, int td = 0);  // td: time_dim (0 = the kind's default)
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st);
+                       hipStream_t st, int td = 0);
 #define TDX_PACK_MAX 13
 struct TdxPackBatch {
   const float* w[TDX_PACK_MAX];
@@ -47,7 +47,7 @@ int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int spli
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64 = nullptr);
+                          const int64_t* t_i64 = nullptr, int td = 0);
 extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd_kernel (int64 t from the workspace copy)
 extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,

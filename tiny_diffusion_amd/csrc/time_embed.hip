@@ -163,34 +163,92 @@ linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ w,
   }
 }
 
-static int time_embed_fwd_laion(const int64_t* t, const float* cond, const float* const* P, float* sin,
-                                float* pre, float* emb, float* t1, float* t2, float* t3, int B,
-                                hipStream_t st) {
+// out = act(in) W^T + b (+ addend) for an input width td = 256 R, R = 1..4 (time_dim is a constructor
+// argument of the reference's NoiseModel: diffusion.py:16, conditional_diffusion_laion.py:236)
+template <bool IN_SILU>
+static int linear_rows(const float* in, const float* w, const float* b, const float* addend, float* out, int B,
+                       int O, int td, hipStream_t st) {
   constexpr int NB = 4;
-  const int gb = cdiv(B, NB);
-  sinusoid_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(t, sin, B, TDL);
+  const dim3 grid(cdiv(B, NB), O / 64);
+  switch (td / 256) {
+    case 1: linear_rows_kernel<1, NB, IN_SILU><<<grid, 256, 0, st>>>(in, w, b, addend, out, B, O); break;
+    case 2: linear_rows_kernel<2, NB, IN_SILU><<<grid, 256, 0, st>>>(in, w, b, addend, out, B, O); break;
+    case 3: linear_rows_kernel<3, NB, IN_SILU><<<grid, 256, 0, st>>>(in, w, b, addend, out, B, O); break;
+    case 4: linear_rows_kernel<4, NB, IN_SILU><<<grid, 256, 0, st>>>(in, w, b, addend, out, B, O); break;
+    default: return TDX_E_SHAPE;
+  }
   TDX_CHECK_LAUNCH();
-  linear_rows_kernel<3, NB, false><<<dim3(gb, TDL / 64), 256, 0, st>>>(sin, P[TDX_P_TE0_W], P[TDX_P_TE0_B],
-                                                                       nullptr, pre, B, TDL);
+  return 0;
+}
+
+static int time_embed_fwd_laion(const int64_t* t, const float* cond, const float* const* P, float* sin,
+                                float* pre, float* emb, float* t1, float* t2, float* t3, int B, int td,
+                                hipStream_t st) {
+  sinusoid_kernel<<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(t, sin, B, td);
   TDX_CHECK_LAUNCH();
-  linear_rows_kernel<3, NB, true><<<dim3(gb, TDL / 64), 256, 0, st>>>(pre, P[TDX_P_TE2_W], P[TDX_P_TE2_B],
-                                                                      cond, emb, B, TDL);
-  TDX_CHECK_LAUNCH();
+  int rc = linear_rows<false>(sin, P[TDX_P_TE0_W], P[TDX_P_TE0_B], nullptr, pre, B, td, td, st);
+  if (rc) return rc;
+  rc = linear_rows<true>(pre, P[TDX_P_TE2_W], P[TDX_P_TE2_B], cond, emb, B, td, td, st);
+  if (rc) return rc;
   float* dst[3] = {t1, t2, t3};
   const int width[3] = {64, 128, 256};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k) {
-    linear_rows_kernel<3, NB, false><<<dim3(gb, width[k] / 64), 256, 0, st>>>(emb, P[pw[k]], P[pw[k] + 1],
-                                                                              nullptr, dst[k], B, width[k]);
+    rc = linear_rows<false>(emb, P[pw[k]], P[pw[k] + 1], nullptr, dst[k], B, width[k], td, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// kind 0 at a width other than 256: pre = w1 * float(t) + b1 (Linear(1, td)), tf = float(t)
+__global__ void time_l1_fwd_kernel(const int64_t* __restrict__ t, const float* __restrict__ w1,
+                                   const float* __restrict__ b1, float* __restrict__ pre, float* __restrict__ tf,
+                                   int B, int td) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * td) return;
+  const int n = i / td, j = i - n * td;
+  const float v = (float)t[n];
+  pre[i] = fmaf(w1[j], v, b1[j]);
+  if (tf && j == 0) tf[n] = v;
+}
+
+// emb[n][:] += E[y[n]][:]   (nn.Embedding lookup added to the time embedding, conditional_diffusion.py:121-125)
+__global__ void add_class_emb_kernel(float* __restrict__ emb, const float* __restrict__ cls,
+                                     const int64_t* __restrict__ y, int B, int td) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * td) return;
+  const int n = i / td, j = i - n * td;
+  emb[i] += cls[(size_t)y[n] * td + j];
+}
+
+static int time_embed_fwd_generic0(const int64_t* t, const int64_t* y, const float* const* P, float* tf,
+                                   float* pre, float* emb, float* t1, float* t2, float* t3, int B, int td,
+                                   hipStream_t st) {
+  time_l1_fwd_kernel<<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(t, P[TDX_P_TE0_W], P[TDX_P_TE0_B], pre, tf, B, td);
+  TDX_CHECK_LAUNCH();
+  int rc = linear_rows<true>(pre, P[TDX_P_TE2_W], P[TDX_P_TE2_B], nullptr, emb, B, td, td, st);
+  if (rc) return rc;
+  if (y) {
+    add_class_emb_kernel<<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(emb, P[TDX_P_CLASS_EMB], y, B, td);
     TDX_CHECK_LAUNCH();
+  }
+  float* dst[3] = {t1, t2, t3};
+  const int width[3] = {128, 256, 512};
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k) {
+    rc = linear_rows<false>(emb, P[pw[k]], P[pw[k] + 1], nullptr, dst[k], B, width[k], td, st);
+    if (rc) return rc;
   }
   return 0;
 }
 
 int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float* cond,
                        const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
-                       float* t3, int B, hipStream_t st) {
-  if (kind == 1) return time_embed_fwd_laion(t, cond, P, sin, pre, emb, t1, t2, t3, B, st);
+                       float* t3, int B, hipStream_t st, int td) {
+  if (td <= 0) td = kind == 1 ? TDL : TD;
+  if (td % 256 || td > 1024) return TDX_E_SHAPE;
+  if (kind == 1) return time_embed_fwd_laion(t, cond, P, sin, pre, emb, t1, t2, t3, B, td, st);
+  if (td != TD) return time_embed_fwd_generic0(t, y, P, sin, pre, emb, t1, t2, t3, B, td, st);
   time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
                                               P[TDX_P_TE2_B], P[TDX_P_CLASS_EMB], pre, emb, sin);
   TDX_CHECK_LAUNCH();
@@ -238,14 +296,14 @@ __global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __res
 __global__ void __launch_bounds__(256)
 time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
                    const float* __restrict__ tf, float* __restrict__ dw1, float* __restrict__ db1,
-                   int B) {
+                   int B, int td) {
   __shared__ float red[2][8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cl;
   float sw = 0.f, sb = 0.f;
 #pragma unroll 4
   for (int n = sl; n < B; n += 8) {
-    const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
+    const float gp = g_h[(size_t)n * td + j] * silu_grad_f(pre[(size_t)n * td + j]);
     sw = fmaf(gp, tf[n], sw);
     sb += gp;
   }
@@ -347,13 +405,13 @@ __global__ void silu_kernel(const float* __restrict__ pre, float* __restrict__ h
 
 // dE[c][j] = sum_{n : y[n] == c} g_emb[n][j]   (nn.Embedding backward, fixed order)
 __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int64_t* __restrict__ y,
-                                     float* __restrict__ de, int B, int ncls) {
+                                     float* __restrict__ de, int B, int ncls, int td) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncls * TD) return;
-  const int c = idx / TD, j = idx - c * TD;
+  if (idx >= ncls * td) return;
+  const int c = idx / td, j = idx - c * td;
   float s = 0.f;
   for (int n = 0; n < B; ++n)
-    if ((int)y[n] == c) s += g_emb[(size_t)n * TD + j];
+    if ((int)y[n] == c) s += g_emb[(size_t)n * td + j];
   de[idx] = s;
 }
 
@@ -361,28 +419,28 @@ __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int6
 // no gradient flows to them
 static int time_embed_bwd_laion(const float* const* P, float* const* G, const float* sin, const float* pre,
                                 const float* emb, const float* g_t1, const float* g_t2, const float* g_t3,
-                                float* scratch, int B, hipStream_t st) {
+                                float* scratch, int B, int td, hipStream_t st) {
   float* g_emb = scratch;
-  float* h = scratch + (size_t)B * TDL;
-  float* g_h = scratch + (size_t)2 * B * TDL;
+  float* h = scratch + (size_t)B * td;
+  float* g_h = scratch + (size_t)2 * B * td;
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int ok[3] = {64, 128, 256};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k) {
-    lin_wgrad_kernel<<<cdiv(ok[k] * TDL, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], TDL, ok[k]);
+    lin_wgrad_kernel<<<cdiv(ok[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], td, ok[k]);
     TDX_CHECK_LAUNCH();
-    lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], TDL, k > 0, ok[k]);
+    lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], td, k > 0, ok[k]);
     TDX_CHECK_LAUNCH();
   }
-  silu_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(pre, h, B * TDL);
+  silu_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(pre, h, B * td);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TDL, TDL, TDL);
+  lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, td, td, td);
   TDX_CHECK_LAUNCH();
-  lin_dgrad_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TDL, TDL, 0, TDL);
+  lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, td, td, 0, td);
   TDX_CHECK_LAUNCH();
-  silu_bwd_kernel<<<cdiv(B * TDL, 256), 256, 0, st>>>(g_h, pre, B * TDL);
+  silu_bwd_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_h, pre, B * td);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TDL * TDL, 256), 256, 0, st>>>(g_h, sin, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, TDL, TDL, TDL);
+  lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_h, sin, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, td, td, td);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -392,36 +450,37 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64) {
+                          const int64_t* t_i64, int td) {
+  if (td <= 0) td = TD;
   float* g_emb = scratch;
-  float* h = scratch + (size_t)B * TD;
-  float* g_h = scratch + (size_t)2 * B * TD;
+  float* h = scratch + (size_t)B * td;
+  float* g_h = scratch + (size_t)2 * B * td;
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
   for (int k = 0; k < 3; ++k) {
-    lin_wgrad_kernel<<<cdiv(widths[k] * TD, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
-                                                                widths[k], TD, ldg[k]);
+    lin_wgrad_kernel<<<cdiv(widths[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
+                                                                widths[k], td, ldg[k]);
     TDX_CHECK_LAUNCH();
-    lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, widths[k], TD, k > 0,
+    lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, widths[k], td, k > 0,
                                                         ldg[k]);
     TDX_CHECK_LAUNCH();
   }
   if (ncls > 0 && y) {
-    class_emb_bwd_kernel<<<cdiv(ncls * TD, 256), 256, 0, st>>>(g_emb, y, G[TDX_P_CLASS_EMB], B, ncls);
+    class_emb_bwd_kernel<<<cdiv(ncls * td, 256), 256, 0, st>>>(g_emb, y, G[TDX_P_CLASS_EMB], B, ncls, td);
     TDX_CHECK_LAUNCH();
   }
-  silu_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(pre, h, B * TD);
+  silu_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(pre, h, B * td);
   TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(TD * TD, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, TD, TD, TD);
+  lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, td, td, td);
   TDX_CHECK_LAUNCH();
-  lin_dgrad_kernel<<<cdiv(B * TD, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, TD, TD, 0, TD);
+  lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, td, td, 0, td);
   TDX_CHECK_LAUNCH();
-  if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer)
-    time_l1_bwd_i64_dbg_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B,
+  if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer && td == TD)
+    time_l1_bwd_i64_dbg_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B,
                                                         g_tdx_diag_buffer);
-  else if (g_tdx_time_l1_impl == 1 && t_i64)
-    time_l1_bwd_i64_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  else if (g_tdx_time_l1_impl == 1 && t_i64 && td == TD)
+    time_l1_bwd_i64_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   else
-    time_l1_bwd_kernel<<<TD / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+    time_l1_bwd_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, td);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -429,11 +488,13 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st) {
-  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, st);
+                       hipStream_t st, int td) {
+  if (td <= 0) td = kind == 1 ? TDL : TD;
+  if (td % 256 || td > 1024) return TDX_E_SHAPE;
+  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st);
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int widths[3] = {128, 256, 512};
-  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t);
+  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t, td);
 }
 
 // emb only (kind-0 formula): the latent model applies its own projection widths

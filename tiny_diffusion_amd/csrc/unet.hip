@@ -65,8 +65,14 @@ constexpr int N_STAGES = 15;
 // conditional_diffusion_laion.py:304-332), so any input side hw = 32 * k / 4 (a multiple of 8, >= 32)
 // runs through the same code: every resolution of the table scales by hw / 32.  The MNIST network
 // resizes to fixed sizes (7->8, 14->16, 28->32, 32->28: diffusion.py:135-159): 28 only.
-bool make_spec(int kind, int hw, NetSpec* out) {
+bool make_spec(int kind, int hw, int time_dim, NetSpec* out) {
   NetSpec S = SPECS[kind];
+  // time_dim is a constructor argument of the reference's NoiseModel (diffusion.py:16,
+  // conditional_diffusion_laion.py:236); the time-path kernels take multiples of 256 up to 1024
+  if (time_dim > 0) {
+    if (time_dim % 256 || time_dim > 1024) return false;
+    S.time_dim = time_dim;
+  }
   if (hw <= 0 || hw == S.hw0) { *out = S; return true; }
   if (kind != 1 || hw % 8 || hw < 32 || hw > 512) return false;
   auto sc = [&](int v) { return (int)((int64_t)v * hw / 32); };
@@ -186,12 +192,18 @@ extern "C" int tdx_unet_create_ex(tdx_unet** out, int max_batch, int kind, int n
 }
 
 extern "C" int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int num_classes, int hw) {
-  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2 || hw < 0) return TDX_E_BADARG;
+  return tdx_unet_create_full(out, max_batch, kind, num_classes, hw, 0);
+}
+
+extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int num_classes, int hw,
+                                    int time_dim) {
+  if (!out || max_batch <= 0 || num_classes < 0 || kind < 0 || kind > 2 || hw < 0 || time_dim < 0) return TDX_E_BADARG;
+  if (kind == TDX_UNET_LATENT_MLP && time_dim != 0 && time_dim != 256) return TDX_E_SHAPE;
   if (kind == TDX_UNET_LAION && num_classes != 0) return TDX_E_BADARG;
   if (kind == TDX_UNET_LATENT_MLP && num_classes <= 0) return TDX_E_BADARG;
   NetSpec spec_hw;
   if (kind != TDX_UNET_LATENT_MLP) {
-    if (!make_spec(kind, hw, &spec_hw)) return TDX_E_SHAPE;
+    if (!make_spec(kind, hw, time_dim, &spec_hw)) return TDX_E_SHAPE;
     // every unit must be addressable at max_batch (32-bit buffer offsets: tdx_conv3x3_shape_ok)
     const NetSpec& S = spec_hw;
     for (int i = 0; i < 13; ++i)
@@ -503,7 +515,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   }
 
   RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],
-                        ws + L.tp[1], ws + L.tp[2], B, st));
+                        ws + L.tp[1], ws + L.tp[2], B, st, S.time_dim));
   RC(tdx_initial_conv_fwd(x, P[TDX_P_INIT_W], P[TDX_P_INIT_B], ws + L.x0, B, S.hw0, S.hw0, S.in_ch,
                           S.x0_real, st));
 
@@ -794,7 +806,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     return tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
                               u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
                               P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2);
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2, S.time_dim);
   };
   // first unit of an encoder level below the top, or the bottleneck (units 6, 4, 2): its input is a
   // pooled tensor; route the gradient through the max-pool and add the skip-path gradient

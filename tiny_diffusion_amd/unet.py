@@ -119,13 +119,14 @@ def backward_stage_params(cond: bool, time_name: str = "time_embedding", init_na
 class _Plan:
     """One tdx_unet handle + workspace per (device, batch size)."""
 
-    def __init__(self, batch: int, num_classes: int, device: torch.device, kind: int = KIND_MNIST, hw: int = 0):
+    def __init__(self, batch: int, num_classes: int, device: torch.device, kind: int = KIND_MNIST, hw: int = 0,
+                 time_dim: int = 0):
         self.batch = batch
         self.device = device
         self.hw = hw
         h = C.c_void_p()
         with torch.cuda.device(device):
-            check(lib.tdx_unet_create_hw(C.byref(h), batch, kind, num_classes, hw), "tdx_unet_create_hw")
+            check(lib.tdx_unet_create_full(C.byref(h), batch, kind, num_classes, hw, time_dim), "tdx_unet_create_full")
         self.handle = h
         self.ws_bytes = lib.tdx_unet_workspace_bytes(h, batch, MODE_TRAIN)
         if self.ws_bytes == 0:
@@ -211,9 +212,11 @@ class NoiseModelBase(nn.Module):
 
     def __init__(self, time_dim: Optional[int] = None, num_classes: int = 0, arch: _Arch = ARCH_MNIST):
         super().__init__()
-        time_dim = arch.time_dim if time_dim is None else time_dim
-        if time_dim != arch.time_dim:
-            raise ValueError(f"libtdx is built for time_dim={arch.time_dim} (reference default)")
+        time_dim = arch.time_dim if time_dim is None else int(time_dim)
+        # the reference accepts any width (diffusion.py:16-25); the time-path kernels read rows as
+        # 256-float segments: multiples of 256 up to 1024 (the latent MLP: its default only)
+        if time_dim % 256 or not 256 <= time_dim <= 1024 or (arch.kind == KIND_LATENT and time_dim != arch.time_dim):
+            raise ValueError(f"time_dim must be a multiple of 256 in [256, 1024] (reference default {arch.time_dim})")
         if arch.kind == KIND_LAION and num_classes:
             raise ValueError("the LAION model is conditioned on text embeddings, not class labels")
         self.time_dim = time_dim
@@ -318,7 +321,8 @@ class NoiseModelBase(nn.Module):
         key = (dev, batch) if not hw else (dev, batch, hw)
         p = self._plans.get(key)
         if p is None:
-            p = _Plan(batch, self.num_classes, device, self._arch.kind, hw)
+            p = _Plan(batch, self.num_classes, device, self._arch.kind, hw,
+                      0 if self.time_dim == self._arch.time_dim else self.time_dim)
             self._plans[key] = p
         return p
 
