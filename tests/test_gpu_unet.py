@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu as R  # noqa: E402
 from oracle.weights import make_state_dict  # noqa: E402
-from parity_helpers import (gpu_pool_routing as _gpu_pool_routing,  # noqa: E402
+from parity_helpers import (gpu_pool_routing as _gpu_pool_routing, gpu_relu_masks,  # noqa: E402
                             grad_precision_failures as _grad_precision_failures, is_pre_bn_bias, rel_mse)
 
 REL_MSE_TOL = 1e-9
@@ -537,8 +537,10 @@ def test_time_dim_constructor_argument(time_dim):
         loss.backward()
         cpu_args = (sd, x, t, noise, y)
         pidx = _gpu_pool_routing(m, B, cpu_args, training)
-        loss_ref, eps_ref, g32, _ = R.train_step_grads(*cpu_args, training=training, pool_idx=pidx)
-        _, _, g64, _ = R.train_step_grads(*cpu_args, training=training, dtype=torch.float64, pool_idx=pidx)
+        masks, _ = gpu_relu_masks(m, B, cpu_args, training, pool_idx=pidx)   # sub-gradient choices of the GPU run
+        kw = dict(training=training, pool_idx=pidx, relu_masks=masks)
+        loss_ref, eps_ref, g32, _ = R.train_step_grads(*cpu_args, **kw)
+        _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, **kw)
         assert rel_mse(eps.detach(), eps_ref) < REL_MSE_TOL
         assert abs(loss.item() - loss_ref.item()) < 2e-5 * loss_ref.item()
         bad = _grad_precision_failures({k: p.grad for k, p in m.named_parameters()}, g32, g64, training)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# rocprofv3 evidence of one round, run ON the GPU box from the repo root (gpurun -- 'bash tools/collect_evidence.sh r02'):
+# kernel stats of the roofline leg, the three PMC passes over it (FETCH_SIZE, WRITE_SIZE, MfmaUtil: one counter
+# set per pass, never together with a trace domain), the kernel trace of the training leg and the kernel stats of
+# the default bench command.  Everything lands under gpurun_out/<tag>_*; tools/rocpd_export.py, tools/insitu.py,
+# tools/pmc_traffic.py and tools/pmc_summary.py turn it into the files kept under profiles/.
+set -o pipefail
+tag=${1:-r02}
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+run() { echo "[evidence] $*"; "$@"; }
+run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_roof -- python3 bench.py --roofline-only > gpurun_out/${tag}_roof.json 2> gpurun_out/${tag}_roof.err && echo roof ok &&
+run rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_f -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_f.err && echo pmc_f ok &&
+run rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_w -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_w.err && echo pmc_w ok &&
+run rocprofv3 --pmc MfmaUtil --output-format csv -d gpurun_out/${tag}_pmc_mfma -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_mfma.err && echo pmc_mfma ok &&
+run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -- python3 bench.py --train-only --steps 30 --warmup 5 > gpurun_out/${tag}_train.json 2> gpurun_out/${tag}_train.err && echo train ok &&
+run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bench -- python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_bench.err && echo bench ok
+rc=$?
+# the per-dispatch traces of the long legs are large (two 1000-step chains): keep the stats only
+find gpurun_out/${tag}_bench gpurun_out/${tag}_roof -name "*kernel_trace.csv" -delete 2>/dev/null
+du -sh gpurun_out/${tag}_* 2>/dev/null
+exit $rc

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Per-kernel average of one rocprofv3 --pmc counter (csv output) over the conv launches of
+`bench.py --roofline-only`:  python tools/pmc_summary.py <dir> <COUNTER> <out.txt>"""
+import collections
+import csv
+import glob
+import sys
+
+d, counter, out = sys.argv[1:4]
+f = glob.glob(d + "/*/*counter_collection.csv")[0]
+agg = collections.defaultdict(lambda: [0.0, 0, 1e30, -1e30])
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] == counter and ("conv3x3" in r["Kernel_Name"] or "wgrad_reduce" in r["Kernel_Name"]):
+        a = agg[r["Kernel_Name"].split("(")[0]]
+        v = float(r["Counter_Value"])
+        a[0] += v; a[1] += 1; a[2] = min(a[2], v); a[3] = max(a[3], v)
+lines = [f"{counter} per kernel, rocprofv3 --pmc {counter} --output-format csv -- python3 bench.py --roofline-only",
+         "(gfx950 has no section of its own in ROCm 7.2's derived-counter files: derived metrics use the gfx94x formulas)", ""]
+for k, (tot, n, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    lines.append(f"{k:64s} n={n:4d} avg={tot / n:9.2f} min={lo:9.2f} max={hi:9.2f}")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
