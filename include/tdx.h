@@ -349,6 +349,18 @@ int tdx_unet_create_hw(tdx_unet** out, int max_batch, int kind, int num_classes,
  * kind's default (256 / 768), else a multiple of 256 up to 1024 (the text embeddings of kind 1 have that
  * width too).  TDX_E_SHAPE otherwise. */
 int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int num_classes, int hw, int time_dim);
+/* Synchronised BatchNorm for data-parallel training (an addition: the reference has no
+ * distributed code).  With a callback installed, every train-mode BatchNorm of the plan takes its
+ * statistics over the GLOBAL batch: the forward hands `buffer` = [sum x (C) | sum x^2 (C) | count]
+ * (doubles, device memory owned by the caller, >= 2*1024 + 1 of them) to `fn`, which must all-reduce
+ * (SUM) its first n elements across ranks on `stream` (ordered like a kernel: no host wait needed) and
+ * return 0; the backward does the same with [sum gz | sum gz*xhat | rows].  dgamma / dbeta keep local
+ * sums (the gradient all-reduce averages them).  An N-rank step then equals the single-process step on
+ * the concatenated batch.  fn == NULL restores rank-local statistics (the default, DistributedDataParallel
+ * semantics).  Not capturable in a graph. */
+typedef int (*tdx_allreduce_fn)(void* user, double* device_buffer, int n, tdx_stream_t stream);
+int tdx_unet_set_bn_sync(tdx_unet* u, tdx_allreduce_fn fn, void* user, double* buffer);
+
 /* Arithmetic of the plan's 3x3 convolutions: TDX_PREC_F32 (default: exact fp32 MFMA) or TDX_PREC_BF16
  * (bf16 operands, fp32 accumulation and storage; see the bf16 section above).  Call before a forward;
  * a backward must run in the precision of its forward (TDX_E_STATE otherwise).  Not for kind 2. */

@@ -4,7 +4,7 @@
 // file turns them into per-channel scale/shift that CONSUMERS apply on load
 // (relu(y*scale+shift)), so the normalised activation is never written to HBM.
 // Backward: two per-channel reductions over (g, y), then one in-place pass.
-#include "common.h"
+#include "internal.h"
 
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
@@ -107,6 +107,96 @@ extern "C" int tdx_bn_finalize(const float* stats_partial, int tiles, int tile_r
   bn_finalize_kernel<<<cdiv(C, 4), 256, 0, to_stream(stream)>>>(
       stats_partial, tiles, tile_rows, count, C, gamma, beta, running_mean, running_var,
       num_batches_tracked, scale, shift, save_mean, save_rstd, training);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- synchronised BatchNorm (data-parallel training with statistics over the GLOBAL batch) -------
+// The reference has no distributed code; under DistributedDataParallel its BatchNorm2d layers would
+// normalise with rank-local statistics, which is this library's default.  SyncBN is
+// the option that makes an N-rank step equal the single-process step on the concatenated batch:
+//   forward   per-channel (sum x, sum x^2, count) in double from the convolution's tile partials ->
+//             all-reduce(SUM) by the caller's callback -> scale / shift / running statistics from the
+//             global moments;
+//   backward  per-channel (sum gz, sum gz*xhat) in double -> all-reduce(SUM) -> the input gradient
+//             with the global sums and the global count; dgamma / dbeta keep the LOCAL sums (the
+//             gradient all-reduce averages them, like every other parameter gradient).
+// mom: [sum x (C) | sum x^2 (C) | count (1)] doubles.  Sums of squares in double (53 bits) do not suffer
+// the E[x^2]-E[x]^2 cancellation that made the fp32 path merge centred partials.
+__global__ void __launch_bounds__(256)
+bn_moments_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t count, int C,
+                  double* __restrict__ mom) {
+  __shared__ double red[2][4][256];
+  const int c0 = blockIdx.x * 4, sl = threadIdx.x, cl = threadIdx.x & 3;
+  double S[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0};
+  const double inv_full = 1.0 / (double)tile_rows;
+  const double inv_last = 1.0 / (double)(count - (int64_t)(tiles - 1) * tile_rows);
+  for (int t = sl; t < tiles; t += 256) {
+    const float4 st = *reinterpret_cast<const float4*>(stats + ((size_t)t * 2 + 0) * C + c0);
+    const float4 qt = *reinterpret_cast<const float4*>(stats + ((size_t)t * 2 + 1) * C + c0);
+    const double inv = t == tiles - 1 ? inv_last : inv_full;
+    const float sv[4] = {st.x, st.y, st.z, st.w}, qv[4] = {qt.x, qt.y, qt.z, qt.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      S[k] += (double)sv[k];
+      Q[k] += (double)qv[k] + (double)sv[k] * (double)sv[k] * inv;   // sum x^2 of the tile = M2 + S^2 / n
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][k][sl] = S[k]; red[1][k][sl] = Q[k]; }
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if (sl < half) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { red[0][k][sl] += red[0][k][sl + half]; red[1][k][sl] += red[1][k][sl + half]; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && c0 + cl < C) {
+    mom[c0 + cl] = red[0][cl][0];
+    mom[C + c0 + cl] = red[1][cl][0];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) mom[2 * C] = (double)count;
+}
+
+__global__ void bn_finalize_moments_kernel(const double* __restrict__ mom, int C, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                           float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                           float* __restrict__ scale, float* __restrict__ shift,
+                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  const double n = mom[2 * C], mean = mom[c] / n;
+  double var = mom[C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (save_mean) save_mean[c] = (float)mean;
+  if (save_rstd) save_rstd[c] = rstd;
+  if (rmean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    rmean[c] = (1.0f - BN_MOMENTUM) * rmean[c] + BN_MOMENTUM * (float)mean;
+    rvar[c] = (1.0f - BN_MOMENTUM) * rvar[c] + BN_MOMENTUM * (float)unbiased;
+  }
+}
+
+int tdx_bn_moments(const float* stats_partial, int tiles, int tile_rows, int64_t count, int C, double* mom,
+                   hipStream_t st) {
+  if (!stats_partial || !mom || tiles <= 0 || tile_rows <= 0 || count <= 0 || C <= 0 || C % 4) return TDX_E_BADARG;
+  bn_moments_kernel<<<C / 4, 256, 0, st>>>(stats_partial, tiles, tile_rows, count, C, mom);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_bn_finalize_moments(const double* mom, int C, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
+                            float* save_rstd, hipStream_t st) {
+  if (!mom || !gamma || !beta || !scale || !shift || C <= 0) return TDX_E_BADARG;
+  bn_finalize_moments_kernel<<<cdiv(C, 256), 256, 0, st>>>(mom, C, gamma, beta, running_mean, running_var, nbt, scale,
+                                                           shift, save_mean, save_rstd);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -251,6 +341,54 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count
   }
 }
 
+// SyncBN backward, step 2 of 3: the block partials -> LOCAL per-channel sums; dgamma / dbeta take them,
+// mom = [sum gz (C) | sum gz*xhat (C) | rows (1)] in double goes to the all-reduce
+__global__ void __launch_bounds__(256)
+bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, double count, int C,
+                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                   double* __restrict__ mom) {
+  __shared__ double red[2][4][256];
+  const int c0 = blockIdx.x * 4, sl = threadIdx.x, cl = threadIdx.x & 3;
+  const int c = c0 + cl;
+  double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  for (int t = sl; t < nblk; t += 256) {
+    const float4 p1 = *reinterpret_cast<const float4*>(partial + ((size_t)t * 2 + 0) * C + c0);
+    const float4 p2 = *reinterpret_cast<const float4*>(partial + ((size_t)t * 2 + 1) * C + c0);
+    a1[0] += (double)p1.x; a1[1] += (double)p1.y; a1[2] += (double)p1.z; a1[3] += (double)p1.w;
+    a2[0] += (double)p2.x; a2[1] += (double)p2.y; a2[2] += (double)p2.z; a2[3] += (double)p2.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][k][sl] = a1[k]; red[1][k][sl] = a2[k]; }
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if (sl < half) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { red[0][k][sl] += red[0][k][sl + half]; red[1][k][sl] += red[1][k][sl + half]; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4 && c < C) {
+    const double s1 = red[0][cl][0], s2 = red[1][cl][0];
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dbias) dbias[c] = 0.f;   // train mode: the batch mean removes the bias gradient
+    mom[c] = s1;
+    mom[C + c] = s2;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) mom[2 * C] = count;
+}
+
+// step 3: coef = {gamma*rstd, S1/N, S2/N} from the all-reduced sums and the global count
+__global__ void bn_bwd_coef_moments_kernel(const double* __restrict__ mom, int C, const float* __restrict__ gamma,
+                                           const float* __restrict__ rstd, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = mom[2 * C];
+  coef[0 * C + c] = gamma[c] * rstd[c];
+  coef[1 * C + c] = (float)(mom[c] / n);
+  coef[2 * C + c] = (float)(mom[C + c] / n);
+}
+
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t n4, int C,
                     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -290,8 +428,20 @@ extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, co
                                const float* shift, const float* save_mean, const float* save_rstd,
                                const float* gamma, float* dgamma, float* dbeta, float* dbias,
                                float* scratch, int training, tdx_stream_t stream) {
+  return tdx_bn_relu_bwd_sync(g, y, rows, C, scale, shift, save_mean, save_rstd, gamma, dgamma, dbeta, dbias, scratch,
+                              training, nullptr, nullptr, nullptr, stream);
+}
+
+// The same with the per-channel sums all-reduced across ranks between the reduction and the apply
+// pass (sync != NULL; train mode only): `mom` is the caller's device buffer of 2*C + 1 doubles.
+int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const float* scale,
+                         const float* shift, const float* save_mean, const float* save_rstd,
+                         const float* gamma, float* dgamma, float* dbeta, float* dbias,
+                         float* scratch, int training, tdx_allreduce_fn sync, void* sync_user, double* mom,
+                         tdx_stream_t stream) {
   if (!g || !y || !scale || !shift || !save_mean || !save_rstd || !gamma || !scratch || rows <= 0)
     return TDX_E_BADARG;
+  if (sync && (!mom || !training)) return TDX_E_BADARG;
   if (C % 4 || C > 1024 || (256 % (C / 4)) != 0) return TDX_E_SHAPE;
   hipStream_t st = to_stream(stream);
   const int rpb = bwd_rows_per_block(rows, C);
@@ -302,10 +452,19 @@ extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, co
   bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
       g, y, rows, C, scale, shift, save_mean, save_rstd, partial, rpb);
   TDX_CHECK_LAUNCH();
-  bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
-                                                     save_rstd, scale, dgamma, dbeta, dbias, coef,
-                                                     training);
-  TDX_CHECK_LAUNCH();
+  if (sync) {
+    bn_bwd_sums_kernel<<<cdiv(C, 4), 256, 0, st>>>(partial, nblk, (double)rows, C, dgamma, dbeta, dbias, mom);
+    TDX_CHECK_LAUNCH();
+    const int rc = sync(sync_user, mom, 2 * C + 1, stream);
+    if (rc) return rc;
+    bn_bwd_coef_moments_kernel<<<cdiv(C, 256), 256, 0, st>>>(mom, C, gamma, save_rstd, coef);
+    TDX_CHECK_LAUNCH();
+  } else {
+    bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(partial, nblk, (double)rows, C, gamma,
+                                                       save_rstd, scale, dgamma, dbeta, dbias, coef,
+                                                       training);
+    TDX_CHECK_LAUNCH();
+  }
   const int64_t n4 = rows * C / 4;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 4096) grid = 4096;

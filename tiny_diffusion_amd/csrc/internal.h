@@ -48,6 +48,16 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
                           const int64_t* t_i64 = nullptr, int td = 0);
+// synchronised BatchNorm pieces (bn.hip); tdx_allreduce_fn: include/tdx.h
+int tdx_bn_moments(const float* stats_partial, int tiles, int tile_rows, int64_t count, int C, double* mom,
+                   hipStream_t st);
+int tdx_bn_finalize_moments(const double* mom, int C, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, int64_t* nbt, float* scale, float* shift, float* save_mean,
+                            float* save_rstd, hipStream_t st);
+int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
+                         float* dbeta, float* dbias, float* scratch, int training, tdx_allreduce_fn sync,
+                         void* sync_user, double* mom, tdx_stream_t stream);
 extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd_kernel (int64 t from the workspace copy)
 extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,

@@ -409,9 +409,12 @@ __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int6
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ncls * td) return;
   const int c = idx / td, j = idx - c * td;
+  // labels are read as the LOW dwords of the int64 copy (4-byte loads; values < num_classes): the one
+  // unexplained miscompute of this path involved 8-byte loads on this stream
+  const int* __restrict__ y32 = reinterpret_cast<const int*>(y);
   float s = 0.f;
   for (int n = 0; n < B; ++n)
-    if ((int)y[n] == c) s += g_emb[(size_t)n * td + j];
+    if (y32[2 * n] == c) s += g_emb[(size_t)n * td + j];
   de[idx] = s;
 }
 

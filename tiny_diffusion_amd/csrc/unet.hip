@@ -167,6 +167,9 @@ struct tdx_unet {
   size_t iss_off[13];
   bool packed;
   int precision, saved_precision;  // TDX_PREC_*: of the next forward / of the saved forward
+  tdx_allreduce_fn bn_sync;        // synchronised BatchNorm: all-reduce callback (null: rank-local statistics)
+  void* bn_sync_user;
+  double* bn_sync_buf;
   int saved_batch, saved_mode;  // state of the last forward (for backward)
   // backward state that survives between tdx_unet_backward calls that split the stages:
   float* g_next;                // where the gradient w.r.t. the next unit's activation lives
@@ -236,6 +239,9 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   u->packed = false;
   u->precision = TDX_PREC_F32;
   u->saved_precision = TDX_PREC_F32;
+  u->bn_sync = nullptr;
+  u->bn_sync_user = nullptr;
+  u->bn_sync_buf = nullptr;
   u->saved_batch = 0;
   u->saved_mode = -1;
   u->g_next = nullptr;
@@ -280,6 +286,15 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
 
 extern "C" int tdx_unet_create(tdx_unet** out, int max_batch, int num_classes) {
   return tdx_unet_create_ex(out, max_batch, 0, num_classes);
+}
+
+extern "C" int tdx_unet_set_bn_sync(tdx_unet* u, tdx_allreduce_fn fn, void* user, double* buffer) {
+  if (!u || (fn && !buffer)) return TDX_E_BADARG;
+  if (!u->spec) return fn ? TDX_E_SHAPE : 0;   // the latent MLP's BatchNorm1d kernels keep local statistics
+  u->bn_sync = fn;
+  u->bn_sync_user = user;
+  u->bn_sync_buf = buffer;
+  return 0;
 }
 
 extern "C" int tdx_unet_set_precision(tdx_unet* u, int precision) {
@@ -523,6 +538,24 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   auto sc = [&](int i) -> const float* { return infer ? nullptr : ws + L.ss[i]; };
   auto sh = [&](int i) -> const float* { return infer ? nullptr : ws + L.ss[i] + S.units[i].cout; };
 
+  // tile partials of unit i -> scale / shift / saved mean, rstd / running statistics; with a SyncBN callback
+  // installed (train mode) the per-channel moments go through the caller's all-reduce first
+  auto finalize_bn = [&](int i, int tiles, int tile_rows, int64_t count) -> int {
+    const UnitDef& d = S.units[i];
+    float* ss = ws + L.ss[i];
+    if (training && u->bn_sync) {
+      RC(tdx_bn_moments(ws + L.stats, tiles, tile_rows, count, d.cout, u->bn_sync_buf, st));
+      RC(u->bn_sync(u->bn_sync_user, u->bn_sync_buf, 2 * d.cout + 1, stream));
+      return tdx_bn_finalize_moments(u->bn_sync_buf, d.cout, P[TDX_P_UNIT0 + 4 * i + 2], P[TDX_P_UNIT0 + 4 * i + 3],
+                                     (float*)buffers[3 * i], (float*)buffers[3 * i + 1], (int64_t*)buffers[3 * i + 2],
+                                     ss, ss + d.cout, ss + 2 * d.cout, ss + 3 * d.cout, st);
+    }
+    return tdx_bn_finalize(ws + L.stats, tiles, tile_rows, count, d.cout, P[TDX_P_UNIT0 + 4 * i + 2],
+                           P[TDX_P_UNIT0 + 4 * i + 3], (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
+                           (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout, ss + 3 * d.cout,
+                           training ? 1 : 0, stream);
+  };
+
   auto run_unit = [&](int i, const float* in) -> int {
     const UnitDef& d = S.units[i];
     const float* wf = u->wpack + u->wf_off[i];
@@ -542,10 +575,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       RC(tdx_conv3x3_fwd_bf16(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, d.in_bn ? sc(i - 1) : nullptr,
                               d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, stream));
       const int rows = tdx_conv3x3_bf16_stat_tile_rows();
-      RC(tdx_bn_finalize(ws + L.stats, cdiv(M, rows), rows, M, d.cout, P[TDX_P_UNIT0 + 4 * i + 2],
-                         P[TDX_P_UNIT0 + 4 * i + 3], (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
-                         (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout, ss + 3 * d.cout,
-                         training ? 1 : 0, stream));
+      RC(finalize_bn(i, cdiv(M, rows), rows, M));
       return 0;
     }
     if (infer) {
@@ -562,13 +592,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
                        bn_on_load ? sc(i - 1) : nullptr, bn_on_load ? sh(i - 1) : nullptr, nullptr, nullptr,
                        ws + L.stats, stream));
     const int tiles = tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout);
-    RC(tdx_bn_finalize(ws + L.stats, tiles,
-                       tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout),
-                       (int64_t)B * d.hw * d.hw, d.cout,
-                       P[TDX_P_UNIT0 + 4 * i + 2], P[TDX_P_UNIT0 + 4 * i + 3],
-                       (float*)buffers[3 * i], (float*)buffers[3 * i + 1],
-                       (int64_t*)buffers[3 * i + 2], ss, ss + d.cout, ss + 2 * d.cout,
-                       ss + 3 * d.cout, training ? 1 : 0, stream));
+    RC(finalize_bn(i, tiles, tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout), (int64_t)B * d.hw * d.hw));
     if (u->materialize && i + 1 < 13 && S.units[i + 1].in_bn)
       RC(tdx_bn_relu_apply(Y, ws + L.A[i], (int64_t)B * d.hw * d.hw, d.cout, ss, ss + d.cout, st));
     return 0;
@@ -705,10 +729,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     float* g = g_next;
     const float* ss = ws + L.ss[i];
     const int64_t rows = (int64_t)B * d.hw * d.hw;
-    RC(tdx_bn_relu_bwd(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
-                       ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
-                       G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
-                       stream));
+    RC(tdx_bn_relu_bwd_sync(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
+                            ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
+                            G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
+                            training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
     // NetSpec says overlap = 0).
     const bool bn_on_load = d.in_bn && (!u->materialize || bf16);

@@ -105,7 +105,8 @@ class TrainStep:
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  process_group=None, bucket_floats: int = 1 << 20, philox_seed: Optional[int] = None,
                  max_grad_norm: Optional[float] = None, cosine_T_max: Optional[int] = None,
-                 cosine_eta_min: float = 0.0, use_graph: bool = False, data_parallel: bool = True):
+                 cosine_eta_min: float = 0.0, use_graph: bool = False, data_parallel: bool = True,
+                 sync_bn: bool = False):
         """``data_parallel=False`` keeps the step rank-local even inside an initialised process group
         (bench.py times it beside the collective step to report what the exchange costs).
 
@@ -133,6 +134,17 @@ class TrainStep:
         self.reducer = BucketedAllReduce(self.flat_grad, self.buckets, process_group, enabled=data_parallel)
         self.world = self.reducer.world
         self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        # sync_bn: BatchNorm statistics over the global batch (26 small all-reduces per
+        # step on the critical chain, on a process group of their own so that they do not queue behind
+        # the gradient buckets of the communication stream)
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn:
+            if use_graph:
+                raise ValueError("sync_bn calls back into the host between launches: not graph-capturable")
+            backend = torch.distributed.get_backend(process_group)
+            ranks = torch.distributed.get_process_group_ranks(process_group) if process_group is not None else None
+            self.bn_pg = torch.distributed.new_group(ranks=ranks, backend=backend)
+            model.set_bn_sync(lambda buf: torch.distributed.all_reduce(buf, group=self.bn_pg))
         self.comm = None  # communication stream (created on first use when there is a collective)
         # use_graph: capture the whole step (randint, q_sample, forward, loss, backward, clip, Adam)
         # into one HIP graph and replay it.  Single rank, noise and t drawn by torch inside the

@@ -23,6 +23,7 @@ from ._lib import lib, check
 
 TIME_DIM = 256
 MODE_TRAIN, MODE_EVAL_GRAD, MODE_INFER = 0, 1, 2
+_BN_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)   # tdx_allreduce_fn
 KIND_MNIST, KIND_LAION, KIND_LATENT = 0, 1, 2
 
 
@@ -135,6 +136,7 @@ class _Plan:
         self.generation = 0      # bumped by every forward that saves state
         self.infer_key = None    # parameter versions the INFER pack was built from
         self.precision = 0       # TDX_PREC_* the handle is set to
+        self.bn_sync = None      # SyncBN callback object installed on the handle
 
     def tensor(self, name: str) -> torch.Tensor:
         """View of a named intermediate inside the workspace (tests / debugging)."""
@@ -241,6 +243,7 @@ class NoiseModelBase(nn.Module):
         self._grad_views = None
         self._buf_epoch = 0
         self._precision = 0   # TDX_PREC_F32
+        self._bn_allreduce = self._bn_cb = self._bn_buf = self._bn_error = None
         self._live_ctx = weakref.WeakSet()   # autograd nodes of this module whose backward has not run yet
 
     def _init_latent(self, arch, time_dim):
@@ -301,6 +304,46 @@ class NoiseModelBase(nn.Module):
     @property
     def compute_dtype(self):
         return torch.bfloat16 if self._precision == 1 else torch.float32
+
+    def set_bn_sync(self, allreduce=None) -> "NoiseModelBase":
+        """Synchronised BatchNorm for data-parallel training (not in the reference, which has no
+        distributed code): ``allreduce(tensor)`` must sum a float64 CUDA tensor in place
+        across ranks, ordered on the current stream (``torch.distributed.all_reduce`` does).  Train-mode
+        statistics and the backward sums are then taken over the global batch, so an N-rank step equals
+        the single-process step on the concatenated batch.  ``None`` restores rank-local statistics."""
+        if allreduce is not None and self._arch.kind == KIND_LATENT:
+            raise ValueError("SyncBN is implemented for the convolutional networks")
+        self._bn_allreduce = allreduce
+        if allreduce is None:
+            self._bn_cb = None
+        else:
+            def cb(user, ptr, n, stream):   # called by libtdx between two launches on `stream`
+                try:
+                    buf = self._bn_buf
+                    if buf is None or ptr != buf.data_ptr() or n > buf.numel():
+                        return -4
+                    allreduce(buf[:n])
+                    return 0
+                except Exception as e:      # an exception cannot cross the C frame: report a status
+                    self._bn_error = e
+                    return -4
+            self._bn_cb = _BN_CALLBACK(cb)
+        for plan in self._plans.values():
+            plan.bn_sync = None
+        return self
+
+    def _apply_bn_sync(self, plan, device):
+        want = self._bn_cb
+        if plan.bn_sync is want:
+            return
+        if want is None:
+            check(lib.tdx_unet_set_bn_sync(plan.handle, None, None, None), "tdx_unet_set_bn_sync")
+        else:
+            if self._bn_buf is None or self._bn_buf.device != device:
+                self._bn_buf = torch.zeros(2 * 1024 + 8, dtype=torch.float64, device=device)
+            check(lib.tdx_unet_set_bn_sync(plan.handle, C.cast(want, C.c_void_p), None, self._bn_buf.data_ptr()),
+                  "tdx_unet_set_bn_sync")
+        plan.bn_sync = want
 
     def _apply_precision(self, plan):
         if plan.precision != self._precision:
@@ -398,6 +441,7 @@ class NoiseModelBase(nn.Module):
             return x.new_empty((0,) + tuple(self._arch.in_shape), dtype=torch.float32), None, MODE_INFER
         plan = self._plan(B, x.device, self._input_hw(x))
         self._apply_precision(plan)
+        self._apply_bn_sync(plan, x.device)
         mode = self._mode() if mode is None else mode
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()

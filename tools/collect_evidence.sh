@@ -8,7 +8,7 @@ set -o pipefail
 tag=${1:-r02}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
-run() { echo "[evidence] $*"; "$@"; }
+run() { echo "[evidence] $*" >&2; "$@"; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_roof -- python3 bench.py --roofline-only > gpurun_out/${tag}_roof.json 2> gpurun_out/${tag}_roof.err && echo roof ok &&
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_f -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_f.err && echo pmc_f ok &&
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_w -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_w.err && echo pmc_w ok &&
