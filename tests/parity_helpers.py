@@ -16,6 +16,66 @@ def is_pre_bn_bias(key):
     return kind == "bias" and idx in ("0", "3") and stage[:3] in ("enc", "dec", "bot")
 
 
+def _plan_of(m, B):
+    return [p for key, p in m._plans.items() if key[1] == B][0]
+
+
+def gpu_pool_idx_raw(m, B):
+    """Arg-max index of every max-pool window exactly as the GPU forward decided it (no check)."""
+    plan = _plan_of(m, B)
+    out = {}
+    for name, unit, H, Cc in (("e1", 1, 28, 128), ("e2", 3, 14, 256), ("e3", 5, 7, 512)):
+        Y = plan.tensor(f"Y{unit}").view(B, H, H, Cc)
+        ss = plan.tensor(f"ss{unit}")
+        a = torch.relu(torch.addcmul(ss[Cc:2 * Cc], Y, ss[:Cc])).permute(0, 3, 1, 2).cpu()
+        out[name] = R.pool_windows(a).argmax(dim=-1, keepdim=True)
+    return out
+
+
+def gpu_relu_masks_raw(m, B):
+    """Active set of every ReLU exactly as the GPU forward decided it (no check)."""
+    plan = _plan_of(m, B)
+    masks = {}
+    for u, (name, (H, Cc)) in enumerate(zip(UNIT_BN, UNIT_SHAPE)):
+        Y = plan.tensor(f"Y{u}").view(B, H, H, Cc)
+        ss = plan.tensor(f"ss{u}")
+        masks[name] = (torch.addcmul(ss[Cc:2 * Cc], Y, ss[:Cc]).permute(0, 3, 1, 2) > 0).cpu()
+    return masks
+
+
+def check_choices(pool_idx, masks, cpu_args, training=True, pool_tol=1e-4, relu_tol=1e-5):
+    """The sub-gradient choices of an implementation may differ from the exact (fp64) ones only at
+    ties: a pooling window whose picked entry is within ``pool_tol`` of the maximum, a ReLU input
+    within ``relu_tol`` of 0 (both relative to the tensor's RMS).  Returns the number of flips."""
+    sd, x, t, noise, y = cpu_args
+    p64, b64 = R.split_state(sd)
+    p64 = {k: v.double() for k, v in p64.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in b64.items()}
+    taps = {}
+    with torch.no_grad():
+        R.unet_forward(p64, b64, x.double(), t, y, training=training, taps=taps, pool_idx=pool_idx)
+    flips = {}
+    for name, idx in (pool_idx or {}).items():
+        w64 = R.pool_windows(taps[name])
+        differ = (idx != w64.argmax(dim=-1, keepdim=True)).squeeze(-1)
+        if differ.any():
+            rms = taps[name].pow(2).mean().sqrt().item()
+            picked = torch.gather(w64, -1, idx)[differ].squeeze(-1)
+            best = w64[differ].max(dim=-1).values
+            gap = (best - picked) / torch.maximum(best.abs(), torch.tensor(rms, dtype=best.dtype))
+            assert gap.max().item() < pool_tol, (name, int(differ.sum()), gap.max().item())
+            flips[name] = int(differ.sum())
+    for name, mask in (masks or {}).items():
+        exact = taps["prebn_act:" + name]
+        differ = mask != (exact > 0)
+        if differ.any():
+            rms = exact.pow(2).mean().sqrt().item()
+            worst = (exact[differ].abs().max() / rms).item()
+            assert worst < relu_tol, (name, int(differ.sum()), worst)
+            flips[name] = int(differ.sum())
+    return flips
+
+
 def gpu_pool_routing(m, B, cpu_args, training=True):
     """Arg-max index of every max-pool window as the GPU forward decided it (from its own
     pre-BN tensors and scale/shift), checked against the exact routing: they may differ

@@ -115,12 +115,87 @@ def _worker(rank, world, port, out, backend):
         torch.distributed.destroy_process_group()
 
 
-def _run(backend):
+def _syncbn_worker(rank, world, port, out, backend):
+    """SyncBN: with BatchNorm statistics (forward) and the backward sums taken over the GLOBAL batch, the
+    two-rank step must equal the single-process step on the concatenated batch - the exact-parity mode
+    SURVEY.md 8(e) names: all-reduced gradient / world == oracle gradient at B = 2 x 8, identical running
+    statistics on both ranks == the oracle's for the global batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
+                                             device_id=torch.device("cuda", dev_index))
+        cpu_group = torch.distributed.new_group(backend="gloo")
+    else:
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        cpu_group = None
+    try:
+        from oracle import ref_cpu as R
+        from oracle.weights import make_state_dict
+        from parity_helpers import check_choices, gpu_pool_idx_raw, gpu_relu_masks_raw, grad_precision_failures
+        from tiny_diffusion_amd.conditional_diffusion import ForwardProcess, NoiseModel
+        from tiny_diffusion_amd.train import TrainStep
+
+        B = 8
+        sd = make_state_dict(6, True)
+        m = NoiseModel()
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        fp = ForwardProcess()
+        ts = TrainStep(m, fp, lr=1e-3, sync_bn=True)
+        assert ts.world == world and ts.sync_bn
+        ts.broadcast_parameters(0)
+        x0, noise, t, y = _shard(rank, B)
+        ts.step(x0.cuda(), y.cuda(), t=t.cuda(), noise=noise.cuda())
+        torch.cuda.synchronize()
+        assert m._bn_error is None, m._bn_error
+        got = ts.flat_grad.cpu() / world
+        # the global batch = the shards in rank order; the sub-gradient choices of each rank's GPU run
+        shards = [_shard(r, B) for r in range(world)]
+        X0, N, T, Y = (torch.cat([s_[i] for s_ in shards]) for i in range(4))
+        X_t = R.q_sample(R.Schedule(), X0, T, N)
+        pool, masks = gpu_pool_idx_raw(m, B), gpu_relu_masks_raw(m, B)
+
+        def gather(v):   # (B, ...) per rank -> (world * B, ...) in rank order
+            parts = [torch.zeros_like(v) for _ in range(world)]
+            torch.distributed.all_gather(parts, v.contiguous(), group=cpu_group)
+            return torch.cat(parts)
+
+        pool = {k: gather(v) for k, v in pool.items()}
+        masks = {k: gather(v.to(torch.uint8)).bool() for k, v in masks.items()}
+        cpu_args = (sd, X_t, T, N, Y)
+        flips = check_choices(pool, masks, cpu_args)          # only ties may differ from the exact choices
+        kw = dict(pool_idx=pool, relu_masks=masks)
+        _, _, g32, bufs = R.train_step_grads(*cpu_args, **kw)
+        _, _, g64, _ = R.train_step_grads(*cpu_args, dtype=torch.float64, **kw)
+        mine = {k: got[lo:hi].view(g64[k].shape) for k, (lo, hi) in ts.offsets.items()}
+        bad = grad_precision_failures(mine, g32, g64, True)
+        assert not bad, (flips, bad)
+        for k, v in m.state_dict().items():   # running statistics of the GLOBAL batch, on every rank
+            if "running_" in k:
+                assert torch.allclose(v.cpu(), bufs[k], rtol=2e-5, atol=2e-5), k
+            if "num_batches" in k:
+                assert int(v) == int(bufs[k])
+        # and the default (rank-local statistics) really is something else: the two modes differ
+        m2 = NoiseModel(); m2.load_state_dict(sd); m2 = m2.cuda().train()
+        ts2 = TrainStep(m2, fp, lr=1e-3)
+        ts2.step(x0.cuda(), y.cuda(), t=t.cuda(), noise=noise.cuda())
+        torch.cuda.synchronize()
+        assert (ts2.flat_grad.cpu() / world - got).norm() > 1e-3 * got.norm()
+        out[rank] = "ok"
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _run(backend, worker=None):
     world = 2
     port = _free_port()
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out, backend), nprocs=world, join=True)
+    mp.spawn(worker or _worker, args=(world, port, out, backend), nprocs=world, join=True)
     assert dict(out) == {0: "ok", 1: "ok"}
 
 
@@ -131,3 +206,12 @@ def test_data_parallel_step_matches_mean_of_shard_gradients():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL variant needs two GPUs")
 def test_data_parallel_step_rccl_two_gpus():
     _run("nccl")
+
+
+def test_sync_batchnorm_two_ranks_equal_the_global_batch_step():
+    _run("gloo", _syncbn_worker)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL variant needs two GPUs")
+def test_sync_batchnorm_rccl_two_gpus():
+    _run("nccl", _syncbn_worker)
