@@ -83,72 +83,91 @@ conv3x3_bf16_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
   const int nk = 9 * (a.Cin / KT);
-  f32x4 ra[AI], rb[BI];
-  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-
-  int cur = 1;
-  for (int kt = -1; kt < nk; ++kt) {
-    unsigned okmask = 0;
-    {
-      const int kn = min(kt + 1, nk - 1);
-      const int cblk = kn / 9, tap = kn - cblk * 9;
-      const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * 4u;
-      const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * KT) * 2u;
+  // Two register stages: at 16x the fp32 matrix rate one K-tile is 16 MFMAs (~0.2 us) per wave while
+  // a global load takes 1-2 us, so the loop is LATENCY-bound unless a tile's loads are issued a whole
+  // iteration before they are needed (measured with one stage: 190 us for a layer whose HBM time is 40).
+  // Iteration kt: issue the loads of tile kt+2 into the free stage, run the MFMAs of tile kt from
+  // LDS[kt&1], convert + store tile kt+1 (loaded during iteration kt-1) into LDS[(kt+1)&1].
+  struct Stage {
+    f32x4 ra[AI], rb[BI], sc, sh;
+    unsigned ok;
+  };
+  Stage S0, S1;
+  auto load_tile = [&](int kt, Stage& S) {
+    const int kn = min(kt, nk - 1);
+    const int cblk = kn / 9, tap = kn - cblk * 9;
+    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * 4u;
+    const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * KT) * 2u;
 #pragma unroll
-      for (int j = 0; j < BI; ++j)
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
+    for (int j = 0; j < BI; ++j)
+      S.rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
+    if (IN_BN) {
+      S.sc = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * 4);
+      S.sh = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * 4);
+    }
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool v = (a_taps[i] >> tap) & 1u;
+      if (IN_BN) ok |= v ? (1u << i) : 0u;
+      S.ra[i] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, v ? a_off[i] : OOB, soff_in, 0));
+    }
+    S.ok = ok;
+  };
+  auto store_tile = [&](const Stage& S, int buf) {
+    __bf16* Ab = As + buf * BM * KTP;
+    __bf16* Bb = Bs + buf * BN * KTP;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      f32x4 v = S.ra[i];
       if (IN_BN) {
-        sc4 = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * 4);
-        sh4 = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * 4);
-      }
+        // padding must stay 0 AFTER the transform (relu(shift) != 0)
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        const bool ok = (a_taps[i] >> tap) & 1u;
-        if (IN_BN) okmask |= ok ? (1u << i) : 0u;
-        ra[i] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? a_off[i] : OOB, soff_in, 0));
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], S.sc[e], S.sh[e]), 0.f);
+        if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      *reinterpret_cast<bf16x4*>(Ab + (a_row + 16 * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
     }
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      *reinterpret_cast<f32x4*>(Bb + (b_row + 32 * j) * KTP + b_ch * 8) = S.rb[j];
+  };
+  auto compute = [&](int buf) {
+    const __bf16* Ab = As + buf * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
+    const __bf16* Bb = Bs + buf * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + im * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + in * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
+    }
+  };
+  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
+    load_tile(kt + 2, Sld);                 // (clamped at the end: a redundant re-load, never stored)
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads at the top: hipcc otherwise sinks them
+    compute(cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt >= 0) {
-      const __bf16* Ab = As + cur * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
-      const __bf16* Bb = Bs + cur * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
-#pragma unroll
-      for (int ks = 0; ks < KT / 16; ++ks) {
-        bf16x8 af[TM], bf[TN];
-#pragma unroll
-        for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + im * 32 * KTP + ks * 16);
-#pragma unroll
-        for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + in * 32 * KTP + ks * 16);
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      __bf16* Ab = As + (cur ^ 1) * BM * KTP;
-      __bf16* Bb = Bs + (cur ^ 1) * BN * KTP;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        f32x4 v = ra[i];
-        if (IN_BN) {
-          // padding must stay 0 AFTER the transform (relu(shift) != 0)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc4[e], sh4[e]), 0.f);
-          if (!((okmask >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        *reinterpret_cast<bf16x4*>(Ab + (a_row + 16 * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
-      }
-#pragma unroll
-      for (int j = 0; j < BI; ++j)
-        *reinterpret_cast<f32x4*>(Bb + (b_row + 32 * j) * KTP + b_ch * 8) = rb[j];
-    }
+    if (kt + 1 < nk) store_tile(Sst, cur ^ 1);
     __syncthreads();
-    cur ^= 1;
+  };
+  load_tile(0, S0);
+  load_tile(1, S1);
+  store_tile(S0, 0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, 0, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
+    iteration(kt + 1, 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
   }
+  if (kt < nk) iteration(kt, 0, S1, S0);
   conv_epilogue<BM, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw), tile_m, m0, n0, wm, wn, l31, half,
                                     tid);
 }
@@ -159,7 +178,7 @@ conv3x3_bf16_kernel(ConvArgs a) {
 // while they are staged: a thread loads 4 pixels x 4 channels (four float4), and writes, per channel,
 // the four pixels as one 8-byte bf16 pack into LDS[channel][pixel].  K-tile = 64 pixels.
 template <int BM, int BN, bool IN_BN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)   // two workgroups per CU (<= 256 registers): latency hiding first
 conv3x3_wgrad_bf16_kernel(WgradArgs a) {
   constexpr int WGN = 2;
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -232,10 +251,19 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
-  f32x4 ra[APASS][4], rb[BPASS][4];
-  unsigned okB = 0;  // bit (q*4 + e): pixel e of group q has its tap inside the image
+  // two register stages, as in conv3x3_bf16_kernel: the loads of pixel-tile kt+2 are in flight while
+  // tile kt is multiplied and tile kt+1 is converted, transposed and stored
+  struct Stage {
+    f32x4 ra[APASS][4], rb[BPASS][4];
+    unsigned okB;  // bit (q*4 + e): pixel e of group q has its tap inside the image
+  };
+  Stage S0, S1;
 
-  auto load_tile = [&](int kt, bool advance) {
+  int tiles_issued = 0;
+  auto load_tile = [&](int kt_req, Stage& S) {
+    const int kt = min(kt_req, nk - 1);           // clamped tail requests re-load the last tile (never stored)
+    const bool advance = kt_req > 0 && kt_req < nk && kt_req == tiles_issued;
+    if (kt_req == tiles_issued) ++tiles_issued;
     const int pbase = p_lo + kt * KT;
     const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 4u;
     const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 4u + tap_shift;
@@ -243,9 +271,9 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     for (int q = 0; q < APASS; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        ra[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  rsrc_dy, a_off[q] + (unsigned)(e * a.Cout) * 4u, soff_a, 0));
-    okB = 0;
+        S.ra[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    rsrc_dy, a_off[q] + (unsigned)(e * a.Cout) * 4u, soff_a, 0));
+    unsigned okB = 0;
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       if (advance) {
@@ -263,20 +291,21 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
         // (pixels past the tensor are refused too: their dy rows are zero, but 0 * garbage may be NaN)
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && pix0 + e < a.M;
         okB |= ok ? (1u << (q * 4 + e)) : 0u;
-        rb[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  rsrc_in, ok ? b_off[q] + (unsigned)(e * a.Cin) * 4u : OOB, soff_b, 0));
+        S.rb[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    rsrc_in, ok ? b_off[q] + (unsigned)(e * a.Cin) * 4u : OOB, soff_b, 0));
         if (++ow == a.W) { ow = 0; if (++oh == a.H) oh = 0; }
       }
     }
+    S.okB = okB;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& S, int buf) {
     __bf16* Ab = As + buf * BM * KTP;
     __bf16* Bb = Bs + buf * BN * KTP;
 #pragma unroll
     for (int q = 0; q < APASS; ++q)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 v = {ra[q][0][c], ra[q][1][c], ra[q][2][c], ra[q][3][c]};
+        const f32x4 v = {S.ra[q][0][c], S.ra[q][1][c], S.ra[q][2][c], S.ra[q][3][c]};
         *reinterpret_cast<bf16x4*>(Ab + (a_c4 * 4 + c) * KTP + q * 4 * APG + a_pg * 4) = __builtin_convertvector(v, bf16x4);
       }
 #pragma unroll
@@ -284,11 +313,11 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
       f32x4 x[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        x[e] = rb[q][e];
+        x[e] = S.rb[q][e];
         if (IN_BN) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) x[e][c] = fmaxf(fmaf(x[e][c], sc4[c], sh4[c]), 0.f);
-          if (!((okB >> (q * 4 + e)) & 1u)) x[e] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding stays 0 after the transform
+          if (!((S.okB >> (q * 4 + e)) & 1u)) x[e] = f32x4{0.f, 0.f, 0.f, 0.f};  // padding stays 0 after the transform
         }
       }
 #pragma unroll
@@ -298,19 +327,9 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
       }
     }
   };
-
-  if (nk > 0) {
-    load_tile(0, false);
-    store_tile(0);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) load_tile(kt + 1, true);
-    __builtin_amdgcn_sched_barrier(0);
-    const __bf16* Ab = As + cur * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
-    const __bf16* Bb = Bs + cur * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
+  auto compute = [&](int buf) {
+    const __bf16* Ab = As + buf * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
+    const __bf16* Bb = Bs + buf * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
 #pragma unroll
     for (int ks = 0; ks < KT / 16; ++ks) {
       bf16x8 af[TM], bf[TN];
@@ -324,11 +343,27 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
         for (int in = 0; in < TN; ++in)
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
+  };
+  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
+    load_tile(kt + 2, Sld);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store_tile(cur ^ 1);
+    compute(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) store_tile(Sst, cur ^ 1);
     __syncthreads();
-    cur ^= 1;
+  };
+  if (nk > 0) {
+    load_tile(0, S0);
+    load_tile(1, S1);
+    store_tile(S0, 0);
   }
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, 0, S1, S0);
+    iteration(kt + 1, 1, S0, S1);
+  }
+  if (kt < nk) iteration(kt, 0, S1, S0);
 
   float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll

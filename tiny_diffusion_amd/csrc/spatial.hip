@@ -562,23 +562,44 @@ int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, floa
 
 // dW[co][ci][tap] = sum_p g[p][co] * x[n][ci][p+tap];  db[co] = sum_p g[p][co]
 // partial[blk][SMALLP_W]: [(co*CIN+ci)*9+tap] then [COR*CIN*9 + co]
-#define ICW_PIX 64   // pixels per block: small, so that the grid has thousands of blocks (the kernels are latency-bound)
+// Pixels per block of the two boundary-convolution weight gradients: small, so that the grid has
+// thousands of blocks (the kernels are latency-bound) - but no smaller than needed for ~4096 blocks:
+// every block writes a partial row of SMALLP_W floats that a second pass sums, and at 64 pixels the
+// (4,64,64) LAION step wrote and re-read 190 MB of partials per kernel (1.5 + 0.8 + 0.9 ms of a 41 ms step).
+static int icw_pix(int64_t M) { return M >= 4096 * 256 ? 256 : M >= 4096 * 128 ? 128 : 64; }
+
+// first pixel of a thread and its (image, row, column); advanced by 4 pixels per iteration without
+// divisions (W >= 4)
+struct PixWalk {
+  int n, oh, ow;
+  __device__ PixWalk(int64_t p, int HW, int W) {
+    n = (int)(p / HW);
+    const int r = (int)(p - (int64_t)n * HW);
+    oh = r / W;
+    ow = r - oh * W;
+  }
+  __device__ void step4(int H, int W) {
+    ow += 4;
+    if (ow >= W) { ow -= W; if (++oh == H) { oh = 0; ++n; } }
+  }
+};
 template <int CIN, int COR>
 __global__ void __launch_bounds__(256)
 initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                          float* __restrict__ partial, int B, int H, int W) {
+                          float* __restrict__ partial, int B, int H, int W, int pix) {
   constexpr int NA = CIN * 9 + 1;
   __shared__ float red[4][NA][IC_CO];
   const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int HW = H * W;
   const int64_t M = (int64_t)B * HW;
-  const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
+  const int64_t p0 = (int64_t)blockIdx.x * pix, p1 = min(p0 + pix, M);
   float acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.f;
-  for (int64_t p = p0 + pg; p < p1; p += 4) {
+  PixWalk pw(min(p0 + pg, M - 1), HW, W);
+  for (int64_t p = p0 + pg; p < p1; p += 4, pw.step4(H, W)) {
     const float gv = g[p * IC_CO + co];
-    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
+    const int n = pw.n, oh = pw.oh, ow = pw.ow, r = oh * W + ow;
     const float* xb = x + (int64_t)n * CIN * HW + r;
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
@@ -603,14 +624,19 @@ initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__
   }
 }
 
-int tdx_small_conv_wgrad_blocks(int B, int H, int W) { return cdiv((int64_t)B * H * W, ICW_PIX); }
+int tdx_small_conv_wgrad_blocks(int B, int H, int W) {
+  const int64_t M = (int64_t)B * H * W;
+  return cdiv(M, icw_pix(M));
+}
 int tdx_small_conv_partial_width(void) { return SMALLP_W; }
 
 int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
                            int B, int H, int W, int cin, int cout_real, hipStream_t st) {
   const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
-  if (cin == 1 && cout_real == 64) initial_conv_wgrad_kernel<1, 64><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
-  else if (cin == 4 && cout_real == 32) initial_conv_wgrad_kernel<4, 32><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W);
+  const int pix = icw_pix((int64_t)B * H * W);
+  if (W < 4) return TDX_E_SHAPE;
+  if (cin == 1 && cout_real == 64) initial_conv_wgrad_kernel<1, 64><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, pix);
+  else if (cin == 4 && cout_real == 32) initial_conv_wgrad_kernel<4, 32><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, pix);
   else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
@@ -743,18 +769,19 @@ int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B,
 template <int CO>
 __global__ void __launch_bounds__(256)
 final_conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ g_out,
-                        float* __restrict__ partial, int B, int H, int W) {
+                        float* __restrict__ partial, int B, int H, int W, int pix) {
   constexpr int NA = CO * 10;
   __shared__ float red[4][NA][IC_CO];
   const int ci = threadIdx.x & 63, pg = threadIdx.x >> 6;
   const int HW = H * W;
   const int64_t M = (int64_t)B * HW;
-  const int64_t p0 = (int64_t)blockIdx.x * ICW_PIX, p1 = min(p0 + ICW_PIX, M);
+  const int64_t p0 = (int64_t)blockIdx.x * pix, p1 = min(p0 + pix, M);
   float acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.f;
-  for (int64_t p = p0 + pg; p < p1; p += 4) {
-    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
+  PixWalk pw(min(p0 + pg, M - 1), HW, W);
+  for (int64_t p = p0 + pg; p < p1; p += 4, pw.step4(H, W)) {
+    const int n = pw.n, oh = pw.oh, ow = pw.ow, r = oh * W + ow;
     float gv[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) gv[co] = g_out[((int64_t)n * CO + co) * HW + r];
@@ -787,8 +814,10 @@ final_conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ 
 int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
                          int B, int H, int W, int cout, hipStream_t st) {
   const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
-  if (cout == 1) final_conv_wgrad_kernel<1><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
-  else if (cout == 4) final_conv_wgrad_kernel<4><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W);
+  const int pix = icw_pix((int64_t)B * H * W);
+  if (W < 4) return TDX_E_SHAPE;
+  if (cout == 1) final_conv_wgrad_kernel<1><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W, pix);
+  else if (cout == 4) final_conv_wgrad_kernel<4><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W, pix);
   else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   int rc = tdx_reduce_partials(partial, dw, nblk, SMALLP_W, cout * 576, st);
