@@ -482,6 +482,8 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
     }
   };
 
+  unsigned long long c0 = 0, r0 = 0;
+  if (a.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   dma_tile(0, 0);
   __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) in front of a barrier)
   int cur = 0;
@@ -519,7 +521,15 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
     __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading tile kt
     cur ^= 1;
   }
+  unsigned long long c1 = 0, r1 = 0;
+  if (a.stamps) { c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime(); }
   conv_epilogue<BM, BN, EPI, SPLITK>(a, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
+  if (a.stamps && tid == 0) {   // in-kernel clock = d(shader cycles) / d(100 MHz ticks) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+    unsigned long long* o = a.stamps + 8 * blockIdx.x;
+    o[0] = c1 - c0; o[1] = r1 - r0;                      // main loop: cycles, 10-ns ticks
+    o[2] = r0; o[3] = r1; o[4] = __builtin_amdgcn_s_memrealtime();  // absolute: loop start, loop end, epilogue end
+    o[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf;  // XCC id
+  }
 #endif
 }
 
@@ -561,6 +571,9 @@ static int g_conv_impl = 0;           // main-loop variant of the non-split laun
                                       // (default: fastest end to end in in-process A/B), 1 two stages,
                                       // 2 two stages + sched_group_barrier interleave
 static int g_conv_dbg = 0;
+static int g_conv_stamp = 0;           // diagnostics: LDS-DMA forward kernels stamp their main loop into the diag buffer
+extern unsigned* g_tdx_diag_buffer;    // time_embed.hip (tdx_diag_set_buffer)
+extern int g_tdx_probe_stamp;
 static int g_conv_dma = 1;             // raw-input convolutions fetch their tiles by LDS-DMA (variant 3)
 static int g_splitk = 1;              // 0: never split K; 1: split K when the grid would not fill the chip
 static int g_splitk_tiles = 260;      // split K when the 64x64 grid has fewer tiles than this (sweep on
@@ -595,6 +608,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "time_l1_impl")) { g_tdx_time_l1_impl = value; return 0; }
   if (!strcmp(key, "input_copy")) { g_tdx_input_copy = value; return 0; }
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
+  if (!strcmp(key, "conv_stamp")) { g_conv_stamp = value; g_tdx_probe_stamp = value; return 0; }
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
@@ -775,6 +789,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   a.splits = 1;
   a.kt_per_split = 9 * (cin / BK);
   a.dbg = g_conv_dbg;
+  a.stamps = g_conv_stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr;
   hipStream_t st = to_stream(stream);
   if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
     int per;

@@ -478,7 +478,7 @@ extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
   a.stats = stats_partial;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)((int64_t)B * H * W);
-  a.splits = 1; a.kt_per_split = 0; a.dbg = 0;
+  a.splits = 1; a.kt_per_split = 0; a.dbg = 0; a.stamps = nullptr;
   hipStream_t st = to_stream(stream);
   // memory-bound: the widest column tile re-reads the input least often
   if (cout % 128 == 0) { a.tilesN = cout / 128; return launch_bf16<128, 128>(a, flags, st); }

@@ -20,6 +20,8 @@ struct ConvArgs {
   int splits, kt_per_split;  // split-K (variant 2): blockIdx.y = split, raw partials to `out`
   int dbg;                   // timing experiments only (tdx_tune_set "conv_dbg"): 1 no barrier,
                              // 2 no LDS stores, 4 no global loads in the main loop -> WRONG results
+  unsigned long long* stamps;  // diagnostics (tools/gpu_clock_probe.py): per workgroup {shader cycles, 100 MHz ticks}
+                               // around the main loop; null in every product launch
 };
 
 // ---------------------------------------------------------------------------

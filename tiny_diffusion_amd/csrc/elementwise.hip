@@ -405,23 +405,32 @@ extern "C" int tdx_adam_step_clip(float* param, const float* grad, float* exp_av
 
 // -------------------------------------------------------------------- probes
 // fp32 MFMA peak: 4 independent 32x32x2 accumulator chains per wave, 4 waves per block.
-__global__ void __launch_bounds__(256) probe_mfma_kernel(float* out, int iters) {
+__global__ void __launch_bounds__(256) probe_mfma_kernel(float* out, int iters, unsigned long long* stamps) {
   f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
   float a = (float)(threadIdx.x & 7) * 0.001f, b = (float)(threadIdx.x & 3) * 0.002f;
+  unsigned long long c0 = 0, r0 = 0;
+  if (stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   for (int i = 0; i < iters; ++i) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
     acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc3, 0, 0, 0);
   }
+  if (stamps && threadIdx.x == 0) {
+    stamps[8 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+    stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
   float s = 0.f;
   for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+extern unsigned* g_tdx_diag_buffer;
+extern int g_tdx_probe_stamp;
 
 extern "C" int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream) {
   if (!out || iters <= 0 || blocks <= 0) return TDX_E_BADARG;
-  probe_mfma_kernel<<<blocks, 256, 0, to_stream(stream)>>>(out, iters);
+  probe_mfma_kernel<<<blocks, 256, 0, to_stream(stream)>>>(
+      out, iters, g_tdx_probe_stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr);
   TDX_CHECK_LAUNCH();
   return 0;
 }

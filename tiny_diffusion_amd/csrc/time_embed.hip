@@ -388,6 +388,7 @@ time_l1_bwd_i64_dbg_kernel(const float* __restrict__ g_h, const float* __restric
   }
 }
 int g_tdx_time_l1_impl = 0;
+int g_tdx_probe_stamp = 0;
 unsigned* g_tdx_diag_buffer = nullptr;  // >= (64*8 + 8*2048) dwords, set by tdx_diag_set_buffer
 extern "C" int tdx_diag_set_buffer(void* p) { g_tdx_diag_buffer = static_cast<unsigned*>(p); return 0; }
 
