@@ -501,6 +501,9 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
     for (int in = 0; in < TN; ++in)
       bf[slot][in] = *reinterpret_cast<const f32x4*>(Bb + in * 32 * BK + frag_pos[ks]);
   };
+  // (Tried in round 2: the two workgroups that share a CU alternating s_setprio every K-tile.  It makes the
+  // sharing of the matrix pipes fair - main loops of 519..551 us instead of 434..561 on a one-round 128x128
+  // launch - and leaves the launch at the same 562 us: the pipe runs at 88 % whoever gets it.)
   for (int kt = 0; kt < nk; ++kt) {
     dma_tile(kt + 1, cur ^ 1);  // clamped at the end: a redundant copy of the last tile, never read
     read_frags(cur, 0, 0);

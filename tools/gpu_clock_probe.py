@@ -68,6 +68,8 @@ blocks, iters = 1024, 8192
 pout = torch.empty(blocks * 256, device=dev)
 run("mfma_probe", lambda: check(lib.tdx_probe_mfma_f32(pout.data_ptr(), iters, blocks, st)), blocks,
     blocks * 4 * iters * 4 * 4096.0)
+DBG = int(os.environ.get("TDX_CONV_DBG", "0"))
+lib.tdx_tune_set(b"conv_dbg", DBG)
 for cin, cout, H in ((512, 128, 16), (1024, 256, 8), (128, 128, 28), (256, 256, 14), (512, 512, 7), (64, 64, 32)):
     M = B * H * H
     x = torch.randn(M * cin, device=dev)
