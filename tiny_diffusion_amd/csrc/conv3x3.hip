@@ -570,6 +570,7 @@ struct TileCfg {
 
 // tuning knobs (tdx_tune_set): 0 = heuristic
 static int g_force_tile = 0;          // 1: 128x128, 2: 128x64, 3: 64x64
+static int g_min_tiles = 256;         // smallest grid a 128-row tile may have (knob conv_min_tiles)
 static int g_conv_impl = 0;           // main-loop variant of the non-split launches: 0 one register stage
                                       // (default: fastest end to end in in-process A/B), 1 two stages,
                                       // 2 two stages + sched_group_barrier interleave
@@ -597,6 +598,7 @@ extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* d
 extern "C" int tdx_tune_set(const char* key, int value) {
   if (!key) return TDX_E_BADARG;
   if (!strcmp(key, "conv_tile")) { g_force_tile = value; return 0; }
+  if (!strcmp(key, "conv_min_tiles")) { g_min_tiles = value > 0 ? value : 256; return 0; }
   if (!strcmp(key, "conv_impl")) { g_conv_impl = value < 0 || value > 2 ? 0 : value; return 0; }
   if (!strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (!strcmp(key, "splitk_tiles")) { g_splitk_tiles = value; return 0; }
@@ -632,7 +634,7 @@ static TileCfg pick_tile(int64_t M, int cout) {
     if (cout % cands[i].bn) continue;
     if (i == 2) return cands[i];
     const int64_t tiles = ((M + cands[i].bm - 1) / cands[i].bm) * (cout / cands[i].bn);
-    if (tiles < 256) continue;  // would leave CUs idle: try a smaller tile
+    if (tiles < g_min_tiles) continue;  // would leave CUs idle (or one lone workgroup per CU): try a smaller tile
     const int64_t rounds = (tiles + 255) / 256;
     if ((double)(rounds * 256) <= 1.035 * (double)tiles) return cands[i];
   }
@@ -792,7 +794,17 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   a.splits = 1;
   a.kt_per_split = 9 * (cin / BK);
   a.dbg = g_conv_dbg;
-  a.stamps = g_conv_stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr;
+  // diagnostics: 1 = every LDS-DMA forward/dgrad launch stamps; M = only training-forward launches of M pixels;
+  // -M = only plain-epilogue (dgrad) launches of M pixels
+  const bool stamp = g_conv_stamp == 1 || (g_conv_stamp > 1 && g_conv_stamp == a.M && stats_partial) ||
+                     (g_conv_stamp < 0 && -g_conv_stamp == a.M && !stats_partial);
+  // 2 = every training-forward launch, each into its own region of 8192 workgroup records (a per-process
+  // slot counter: the tool resets it with conv_stamp = 0)
+  static int slot = 0;
+  if (g_conv_stamp == 0) slot = 0;
+  a.stamps = stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr;
+  if (g_conv_stamp == 2 && stats_partial && g_tdx_diag_buffer && slot < 16)
+    a.stamps = reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) + (size_t)(slot++) * 8 * 8192;
   hipStream_t st = to_stream(stream);
   if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
     int per;
