@@ -93,6 +93,13 @@ int tdx_u8_gather_normalize(const uint8_t* data, const int64_t* idx, float* out,
 int tdx_mse_loss(const float* a, const float* b, float* loss_out, float* d_a,
                  float gscale, int64_t n, tdx_stream_t stream);
 
+/* The same loss and gradient in one multi-block pass + a one-block finish (what the fused training step
+ * uses: the single-block reduction of tdx_mse_loss is latency-bound and sits between forward and backward).
+ * scratch: tdx_mse_scratch_bytes() bytes of device memory, 8-byte aligned.  d_a may be NULL. */
+size_t tdx_mse_scratch_bytes(void);
+int tdx_mse_loss_grad(const float* a, const float* b, float* loss_out, float* d_a, float gscale,
+                      int64_t n, void* scratch, tdx_stream_t stream);
+
 /* Adam, torch defaults (diffusion.py:211/236): one fused pass over a flat
  * parameter buffer, 28 B/param.  step is the 1-based step count. */
 int tdx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

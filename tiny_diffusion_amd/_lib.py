@@ -61,6 +61,8 @@ _SIGS = {
     "tdx_p_sample_step_philox": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_uint64, _ptr]),
     "tdx_u8_gather_normalize": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_float, C.c_float, _ptr]),
     "tdx_mse_loss": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_float, C.c_int64, _ptr]),
+    "tdx_mse_scratch_bytes": (C.c_size_t, []),
+    "tdx_mse_loss_grad": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_float, C.c_int64, _ptr, _ptr]),
     "tdx_adam_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, _ptr]),
     "tdx_adam_clip_scratch_bytes": (C.c_size_t, []),

@@ -258,6 +258,63 @@ extern "C" int tdx_mse_loss(const float* a, const float* b, float* loss_out, flo
   return 0;
 }
 
+// Loss and its gradient in ONE multi-block pass (the training step's form): every block writes its slice of
+// d_a = 2 (a - b) / n * gscale and one double partial of sum (a - b)^2; a second, one-block launch adds the
+// partials in a fixed order.  (The single-block loss kernel above is latency-bound: 28 us for the 200 k
+// elements of the MNIST step and 131 / 520 us for the LAION step at 32 / 64 - on the critical path between
+// forward and backward, where nothing else runs.)  Deterministic: fixed grid, fixed order.
+#define MSE_BLOCKS 512
+__global__ void __launch_bounds__(256)
+mse_loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ d_a,
+                     float scale, int64_t n, double* __restrict__ partials) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    if (d_a) d_a[i] = d * scale;
+    s += (double)d * (double)d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    long long v = __double_as_longlong(s);
+    int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64);
+    int hi = __shfl_xor((int)(v >> 32), o, 64);
+    s += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+mse_finish_kernel(const double* __restrict__ partials, int nblk, float* __restrict__ out, double inv_n) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += partials[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_n);
+}
+
+extern "C" size_t tdx_mse_scratch_bytes(void) { return MSE_BLOCKS * sizeof(double); }
+
+extern "C" int tdx_mse_loss_grad(const float* a, const float* b, float* loss_out, float* d_a, float gscale,
+                                 int64_t n, void* scratch, tdx_stream_t stream) {
+  if (!a || !b || !loss_out || !scratch || n <= 0) return TDX_E_BADARG;
+  hipStream_t st = to_stream(stream);
+  int grid = (int)((n + 1023) / 1024);
+  if (grid > MSE_BLOCKS) grid = MSE_BLOCKS;
+  mse_loss_grad_kernel<<<grid, 256, 0, st>>>(a, b, d_a, 2.0f * gscale / (float)n, n, static_cast<double*>(scratch));
+  TDX_CHECK_LAUNCH();
+  mse_finish_kernel<<<1, 256, 0, st>>>(static_cast<const double*>(scratch), grid, loss_out, 1.0 / (double)n);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------------- Adam
 // torch.optim.Adam defaults, single-tensor formulation:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g

@@ -50,9 +50,12 @@ const NetSpec SPECS[2] = {
       {256, 512, 7, 0, 256}, {512, 512, 7, 1, 512},  {512, 512, 4, 0, 512},  {1024, 256, 8, 0, 1024},
       {256, 256, 8, 1, 256}, {512, 128, 16, 0, 512}, {128, 128, 16, 1, 128}, {256, 64, 32, 0, 256},
       {64, 64, 32, 1, 64}}},
-    // overlap = 0: this network's thin 64-channel layers at 32x32 are close to the HBM roofline and
-    // need the L2s to themselves (measured at B=256: 11.7 ms/step on one stream, 14.4 on three)
-    {4, 32, 32, 64, 32, 0, 768, {32, 16, 8, 4}, {8, 16, 32}, {64, 128, 256},
+    // overlap: in round 1 this network ran 22 % SLOWER on three streams (11.7 -> 14.4 ms at B=256: two GEMMs
+    // thrashing the L2s under its thin 64-channel layers) and was kept on one.  With round 2's weight-gradient
+    // split (half the slab traffic), slab reduction and loss kernels the sign flipped - B=256, one / three
+    // streams: 10.88 / 10.20 ms at 32x32, 39.6 / 37.8 at 64x64, bf16 mode 5.66 / 5.04 and 18.4 / 17.6 - so it
+    // overlaps like the MNIST network (mode 2, helpers only on the third stream: 10.85, no gain).
+    {4, 32, 32, 64, 32, 1, 768, {32, 16, 8, 4}, {8, 16, 32}, {64, 128, 256},
      {{64, 64, 32, 0, 32},   {64, 64, 32, 1, 64},    {64, 128, 16, 0, 64},   {128, 128, 16, 1, 128},
       {128, 256, 8, 0, 128}, {256, 256, 8, 1, 256},  {256, 256, 4, 0, 256},  {512, 256, 8, 0, 512},
       {256, 256, 8, 1, 256}, {384, 128, 16, 0, 384}, {128, 128, 16, 1, 128}, {192, 64, 32, 0, 192},
@@ -180,7 +183,10 @@ struct tdx_unet {
   // they fill the tail of the input-gradient GEMM and overlap the HBM-bound BN/pool/resize
   // kernels of the next unit; fork/join with events, so the caller still sees ONE stream
   bool materialize;             // train: write relu(bn(Y)) of the first conv of every stage (see Layout::A)
-  bool use_streams;             // false: `side` / `side2` alias the caller's stream for the current call
+  int use_streams;              // 0: `side` / `side2` alias the caller's stream; 1: three streams; 2: the weight-
+                                // gradient GEMMs stay on the caller's stream, only the HBM-bound helpers (slab
+                                // reductions, boundary-conv weight gradients' reductions, skip-branch resizes,
+                                // time path) use the third stream
   hipStream_t side_own, side2_own;
   hipStream_t side;
   hipEvent_t ev_dy[13], ev_w[13], ev_join, ev_fork, ev_pack;
@@ -248,7 +254,7 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
   u->materialize = g_tdx_materialize != 0;
-  u->use_streams = g_tdx_streams < 0 ? (u->spec && u->spec->overlap) : g_tdx_streams != 0;
+  u->use_streams = g_tdx_streams < 0 ? (u->spec ? u->spec->overlap : 0) : g_tdx_streams;
   e = hipStreamCreateWithPriority(&u->side_own, hipStreamNonBlocking, lo);
   if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); delete u; return (int)e; }
   for (int i = 0; i < 13; ++i) {
@@ -505,7 +511,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const float* const* P = reinterpret_cast<const float* const*>(params);
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t st = to_stream(stream);
-  u->side = u->use_streams ? u->side_own : st;
+  u->side = u->use_streams == 1 ? u->side_own : st;
   u->side2 = u->use_streams ? u->side2_own : st;
   const int B = batch;
   const bool infer = mode == TDX_MODE_INFER;
@@ -674,7 +680,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   float* const* G = reinterpret_cast<float* const*>(grads);
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t st = to_stream(stream);
-  u->side = u->use_streams ? u->side_own : st;
+  u->side = u->use_streams == 1 ? u->side_own : st;
   u->side2 = u->use_streams ? u->side2_own : st;
   const int B = batch;
   const int training = u->saved_mode == TDX_MODE_TRAIN ? 1 : 0;

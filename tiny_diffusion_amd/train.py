@@ -158,6 +158,7 @@ class TrainStep:
         self._hyper = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._clip_scratch = None
+        self._mse_scratch = None
 
     # ------------------------------------------------------------------ setup
     def _flatten(self):
@@ -253,8 +254,11 @@ class TrainStep:
         mode = MODE_TRAIN if m.training else MODE_EVAL_GRAD
         eps_hat, plan, _ = m._run_forward(x_t, t, y, mode=mode)               # diffusion.py:228
         d_out = torch.empty_like(eps_hat)
-        check(lib.tdx_mse_loss(eps_hat.data_ptr(), noise.data_ptr(), self.loss.data_ptr(), d_out.data_ptr(),
-                               1.0, eps_hat.numel(), st), "tdx_mse_loss")      # diffusion.py:231
+        if self._mse_scratch is None:
+            self._mse_scratch = torch.empty(lib.tdx_mse_scratch_bytes(), dtype=torch.uint8, device=dev)
+        check(lib.tdx_mse_loss_grad(eps_hat.data_ptr(), noise.data_ptr(), self.loss.data_ptr(), d_out.data_ptr(),
+                                    1.0, eps_hat.numel(), self._mse_scratch.data_ptr(), st),
+              "tdx_mse_loss_grad")                                             # diffusion.py:231
         if self.world == 1 and not self.reducer.force:
             m._run_backward(plan, d_out, self.grad_views)                      # diffusion.py:235
         else:
