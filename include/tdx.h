@@ -368,6 +368,13 @@ int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int num_classe
 typedef int (*tdx_allreduce_fn)(void* user, double* device_buffer, int n, tdx_stream_t stream);
 int tdx_unet_set_bn_sync(tdx_unet* u, tdx_allreduce_fn fn, void* user, double* buffer);
 
+/* Stream schedule of the plan's training calls: -1 the network's default, 0 everything on the caller's
+ * stream, 1 three streams (weight-gradient GEMMs and HBM-bound helpers beside the main chain, joined by
+ * events before the call's last stage returns), 2 helpers only.  Capture of a whole training step into a
+ * HIP graph must use 0: hipStreamEndCapture of a capture that forked into the library's low-priority
+ * streams crashed inside the runtime on ROCm 7.2 (segmentation fault, no error code). */
+int tdx_unet_set_streams(tdx_unet* u, int mode);
+
 /* Arithmetic of the plan's 3x3 convolutions: TDX_PREC_F32 (default: exact fp32 MFMA) or TDX_PREC_BF16
  * (bf16 operands, fp32 accumulation and storage; see the bf16 section above).  Call before a forward;
  * a backward must run in the precision of its forward (TDX_E_STATE otherwise).  Not for kind 2. */

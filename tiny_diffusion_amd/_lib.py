@@ -116,6 +116,7 @@ _SIGS = {
     "tdx_unet_create_hw": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_unet_create_full": (C.c_int, [C.POINTER(_ptr), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdx_unet_set_bn_sync": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
+    "tdx_unet_set_streams": (C.c_int, [_ptr, C.c_int]),
     "tdx_unet_set_precision": (C.c_int, [_ptr, C.c_int]),
     "tdx_pack_conv3x3_bf16": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_conv3x3_bf16_stat_tile_rows": (C.c_int, []),

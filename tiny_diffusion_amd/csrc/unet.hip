@@ -303,6 +303,12 @@ extern "C" int tdx_unet_set_bn_sync(tdx_unet* u, tdx_allreduce_fn fn, void* user
   return 0;
 }
 
+extern "C" int tdx_unet_set_streams(tdx_unet* u, int mode) {
+  if (!u || mode < -1 || mode > 2) return TDX_E_BADARG;
+  u->use_streams = mode < 0 ? (u->spec ? u->spec->overlap : 0) : mode;
+  return 0;
+}
+
 extern "C" int tdx_unet_set_precision(tdx_unet* u, int precision) {
   if (!u || (precision != TDX_PREC_F32 && precision != TDX_PREC_BF16)) return TDX_E_BADARG;
   if (!u->spec) return precision == TDX_PREC_F32 ? 0 : TDX_E_SHAPE;  // the latent MLP has no bf16 path

@@ -153,6 +153,11 @@ class TrainStep:
         # are bound by the GPU-side cost of ~100-170 tiny dependent kernels, not by host launches
         # (LAION B=8: 2.18 -> 2.05 ms/step; latent MLP B=128: 0.62 -> 0.68), so it is off by default.
         self.use_graph = use_graph
+        if use_graph:
+            # a captured step runs on ONE stream: ending a capture that forked into the library's helper
+            # streams crashed inside the HIP runtime (ROCm 7.2); small-batch steps, which are what graphs
+            # are for, gain nothing from the overlap anyway
+            model._stream_mode = 0
         self._graph = None
         self._graph_key = None
         self._hyper = None

@@ -137,6 +137,7 @@ class _Plan:
         self.infer_key = None    # parameter versions the INFER pack was built from
         self.precision = 0       # TDX_PREC_* the handle is set to
         self.bn_sync = None      # SyncBN callback object installed on the handle
+        self.stream_mode = -1    # tdx_unet_set_streams mode the handle is set to (-1: the network's default)
 
     def tensor(self, name: str) -> torch.Tensor:
         """View of a named intermediate inside the workspace (tests / debugging)."""
@@ -244,6 +245,7 @@ class NoiseModelBase(nn.Module):
         self._buf_epoch = 0
         self._precision = 0   # TDX_PREC_F32
         self._bn_allreduce = self._bn_cb = self._bn_buf = self._bn_error = None
+        self._stream_mode = -1   # -1 default schedule; 0 single stream (required while a step is captured in a graph)
         self._live_ctx = weakref.WeakSet()   # autograd nodes of this module whose backward has not run yet
 
     def _init_latent(self, arch, time_dim):
@@ -345,6 +347,12 @@ class NoiseModelBase(nn.Module):
                   "tdx_unet_set_bn_sync")
         plan.bn_sync = want
 
+    def _apply_streams(self, plan):
+        want = self._stream_mode
+        if plan.stream_mode != want:
+            check(lib.tdx_unet_set_streams(plan.handle, want), "tdx_unet_set_streams")
+            plan.stream_mode = want
+
     def _apply_precision(self, plan):
         if plan.precision != self._precision:
             check(lib.tdx_unet_set_precision(plan.handle, self._precision), "tdx_unet_set_precision")
@@ -442,6 +450,7 @@ class NoiseModelBase(nn.Module):
         plan = self._plan(B, x.device, self._input_hw(x))
         self._apply_precision(plan)
         self._apply_bn_sync(plan, x.device)
+        self._apply_streams(plan)
         mode = self._mode() if mode is None else mode
         pptr, ptens = self._param_ptrs()
         bptr, btens = self._buffer_ptrs()
