@@ -609,6 +609,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "time_proj_early")) { g_tdx_time_proj_early = value != 0; return 0; }
   if (!strcmp(key, "time_stage_diag")) { g_tdx_time_stage = value == 6 ? 6 : 14; return 0; }
   if (!strcmp(key, "time_l1_impl")) { g_tdx_time_l1_impl = value; return 0; }
   if (!strcmp(key, "input_copy")) { g_tdx_input_copy = value; return 0; }

@@ -27,7 +27,10 @@ int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st, int td = 0);
+                       hipStream_t st, int td = 0, bool proj_done = false);
+// one projection's share of the above (time_embed.hip); then tdx_time_embed_bwd(..., proj_done = true)
+int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
+                      const float* g_tk, float* scratch, int B, hipStream_t st, int td = 0);
 #define TDX_PACK_MAX 13
 struct TdxPackBatch {
   const float* w[TDX_PACK_MAX];
@@ -47,7 +50,7 @@ int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int spli
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64 = nullptr, int td = 0);
+                          const int64_t* t_i64 = nullptr, int td = 0, bool proj_done = false);
 // synchronised BatchNorm pieces (bn.hip); tdx_allreduce_fn: include/tdx.h
 int tdx_bn_moments(const float* stats_partial, int tiles, int tile_rows, int64_t count, int C, double* mom,
                    hipStream_t st);
@@ -81,6 +84,7 @@ int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const flo
 // written out (post BN+ReLU) so that convolution and its wgrad run on the LDS-DMA kernels
 extern int g_tdx_materialize;
 extern int g_tdx_time_stage;
+extern int g_tdx_time_proj_early;
 // inference: both halves of a decoder's concatenated input (resize(a) | resize(b + b_addend)) in one launch
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
                           int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st);

@@ -474,10 +474,11 @@ int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t 
 }
 
 // out[i] = sum_b partial[b*stride + i], i < count.  Fixed summation order (deterministic),
-// double accumulation; block = 32 columns x 8 interleaved row slices.
+// double accumulation; block = 32 columns x 8 interleaved row slices.  Columns >= split go to out2
+// (the bias gradient behind the weight gradient in one partial row).
 __global__ void __launch_bounds__(256)
-reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk,
-                       int stride, int count) {
+reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, float* __restrict__ out2,
+                       int split, int nblk, int stride, int count) {
   __shared__ double red[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cl;
@@ -492,13 +493,55 @@ reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ ou
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][cl];
-    out[i] = (float)t;
+    if (i < split) out[i] = (float)t;
+    else out2[i - split] = (float)t;
   }
+}
+
+// First level of a long reduction, IN PLACE: block (c, g) sums the rows congruent to g modulo
+// gridDim.y over its 32 columns and stores the sum into row g.  No block reads what another one
+// writes (rows of another residue class, or other columns), and a block has read all of its rows
+// before it writes (barrier), so nblk rows become gridDim.y rows with no second buffer.  With
+// 3136 rows (B = 256 at 28x28) the one-level kernel above was 18 workgroups walking 392 dependent
+// loads each: 100+ us on the tail of the training step for a 576-float result.
+__global__ void __launch_bounds__(256)
+fold_partials_kernel(float* __restrict__ partial, int nblk, int stride, int count) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl, g = blockIdx.y, G = gridDim.y;
+  double s = 0.0;
+  if (i < count) {
+#pragma unroll 4
+    for (int b = g + sl * G; b < nblk; b += 8 * G) s += (double)partial[(size_t)b * stride + i];
+  }
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    partial[(size_t)g * stride + i] = (float)t;
+  }
+}
+
+constexpr int FOLD_ROWS = 32;
+
+// out[0..split) and out2[0..count-split) from the columns of `partial` (which is consumed)
+static int reduce_partials2(float* partial, float* out, float* out2, int split, int nblk, int stride, int count,
+                            hipStream_t st) {
+  if (nblk > 4 * FOLD_ROWS) {
+    fold_partials_kernel<<<dim3(cdiv(count, 32), FOLD_ROWS), 256, 0, st>>>(partial, nblk, stride, count);
+    TDX_CHECK_LAUNCH();
+    nblk = FOLD_ROWS;
+  }
+  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, out2, split, nblk, stride, count);
+  TDX_CHECK_LAUNCH();
+  return 0;
 }
 
 int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
                         hipStream_t st) {
-  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, nblk, stride, count);
+  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, nullptr, count, nblk, stride, count);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -641,9 +684,7 @@ int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float
   TDX_CHECK_LAUNCH();
   // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
   const int nw = cout_real * cin * 9;
-  int rc = tdx_reduce_partials(partial, dw, nblk, SMALLP_W, nw, st);
-  if (rc) return rc;
-  return tdx_reduce_partials(partial + nw, db, nblk, SMALLP_W, cout_real, st);
+  return reduce_partials2(partial, dw, db, nw, nblk, SMALLP_W, nw + cout_real, st);
 }
 
 // ------------------------------------------------------ final_conv (64 -> CO)
@@ -820,7 +861,5 @@ int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, fl
   else if (cout == 4) final_conv_wgrad_kernel<4><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W, pix);
   else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
-  int rc = tdx_reduce_partials(partial, dw, nblk, SMALLP_W, cout * 576, st);
-  if (rc) return rc;
-  return tdx_reduce_partials(partial + cout * 576, db, nblk, SMALLP_W, cout, st);
+  return reduce_partials2(partial, dw, db, cout * 576, nblk, SMALLP_W, cout * 576 + cout, st);
 }

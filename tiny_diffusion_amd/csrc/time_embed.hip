@@ -423,14 +423,14 @@ __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int6
 // no gradient flows to them
 static int time_embed_bwd_laion(const float* const* P, float* const* G, const float* sin, const float* pre,
                                 const float* emb, const float* g_t1, const float* g_t2, const float* g_t3,
-                                float* scratch, int B, int td, hipStream_t st) {
+                                float* scratch, int B, int td, hipStream_t st, bool proj_done) {
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * td;
   float* g_h = scratch + (size_t)2 * B * td;
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int ok[3] = {64, 128, 256};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 3 && !proj_done; ++k) {
     lin_wgrad_kernel<<<cdiv(ok[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], td, ok[k]);
     TDX_CHECK_LAUNCH();
     lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], td, k > 0, ok[k]);
@@ -454,13 +454,13 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64, int td) {
+                          const int64_t* t_i64, int td, bool proj_done) {
   if (td <= 0) td = TD;
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * td;
   float* g_h = scratch + (size_t)2 * B * td;
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 3 && !proj_done; ++k) {
     lin_wgrad_kernel<<<cdiv(widths[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
                                                                 widths[k], td, ldg[k]);
     TDX_CHECK_LAUNCH();
@@ -492,13 +492,32 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st, int td) {
+                       hipStream_t st, int td, bool proj_done) {
   if (td <= 0) td = kind == 1 ? TDL : TD;
   if (td % 256 || td > 1024) return TDX_E_SHAPE;
-  if (kind == 1) return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st);
+  if (kind == 1)
+    return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st, proj_done);
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int widths[3] = {128, 256, 512};
-  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t, td);
+  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t, td,
+                               proj_done);
+}
+
+// Backward of ONE time projection (k = 0, 1, 2 <-> time_proj1/2/3), for a caller that has the three
+// pixel sums at different times: dW_k, db_k and the projection's contribution to g_emb = scratch[0 : B*td]
+// (k = 0 overwrites, k > 0 accumulates: call in the order 0, 1, 2, the summation order of the whole-path
+// function above, then that function with proj_done).
+int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
+                      const float* g_tk, float* scratch, int B, hipStream_t st, int td) {
+  if (td <= 0) td = kind == 1 ? TDL : TD;
+  if (k < 0 || k > 2 || td % 256 || td > 1024) return TDX_E_SHAPE;
+  const int w = (kind == 1 ? 64 : 128) << k;
+  const int pw = k == 0 ? TDX_P_TP1_W : k == 1 ? TDX_P_TP2_W : TDX_P_TP3_W;
+  lin_wgrad_kernel<<<cdiv(w * td, 256), 256, 0, st>>>(g_tk, emb, G[pw], G[pw + 1], B, w, td, w);
+  TDX_CHECK_LAUNCH();
+  lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_tk, P[pw], scratch, B, w, td, k > 0, w);
+  TDX_CHECK_LAUNCH();
+  return 0;
 }
 
 // emb only (kind-0 formula): the latent model applies its own projection widths

@@ -156,6 +156,7 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+int g_tdx_time_proj_early = 1;  // time_proj backward right behind each pixel sum (0: with the rest, at the end)
 int g_tdx_time_stage = 14;  // backward stage after which the time/class path runs (14, or 6: see DESIGN.md 3.2)
 int g_tdx_input_copy = 0;
 int g_tdx_streams = -1;  // tuning knob "streams": -1 = per-network default (NetSpec::overlap), 0 / 1 = force
@@ -820,6 +821,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     RC(tdx_pixel_sum(ws + L.GS[skip_k], ws + L.gtp[skip_k], B, S.enc_hw[skip_k] * S.enc_hw[skip_k], c_skip,
                      u->side2));
     TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
+    // this projection's weight gradient and its share of g(emb) as soon as its pixel sum exists (levels
+    // arrive in the order time_proj1, 2, 3 = the summation order of tdx_time_embed_bwd): six of the
+    // time path's small kernels leave the tail of the step.  The REST of that path stays after the last
+    // stage (see time_path_bwd).
+    if (g_tdx_time_proj_early)
+      RC(tdx_time_proj_bwd(u->kind, skip_k, P, G, ws + L.emb, ws + L.gtp[skip_k], ws + L.timescr, B, u->side2,
+                           S.time_dim));
     find(gcat)->s2 = k;
     float* gup;
     RC(acquire(gcat, nullptr, &gup));
@@ -842,7 +850,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     return tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
                               u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
                               P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2, S.time_dim);
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2, S.time_dim,
+                              g_tdx_time_proj_early != 0);
   };
   // first unit of an encoder level below the top, or the bottleneck (units 6, 4, 2): its input is a
   // pooled tensor; route the gradient through the max-pool and add the skip-path gradient
