@@ -161,6 +161,16 @@ int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias,
                            const float* out_scale, const float* out_shift,
                            float* scratch, size_t scratch_floats, tdx_stream_t stream);
 size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin, int cout);
+/* The TRAINING form (flags: 0 or TDX_CONV_OUT_STATS; raw input): tdx_conv3x3_fwd, except that shapes whose
+ * tile grid would put one lone workgroup on a CU (few pixels, long K: the bottleneck of the UNet at B = 256)
+ * run as 64x64 tiles with K split, and a second launch reduces the partials in a fixed order, adds the bias
+ * and writes the same [stat_tiles][2][cout] statistics partials.  `scratch`: at least
+ * tdx_conv3x3_train_scratch_floats(...) floats (0 = this shape never splits; scratch may then be NULL).
+ * With the dgrad pack and cin/cout swapped it is the input gradient, as tdx_conv3x3_dgrad. */
+int tdx_conv3x3_fwd_train(const float* in, const float* wpk, const float* bias, float* out, int B, int H, int W,
+                          int cin, int cout, int flags, float* stats_partial, float* scratch,
+                          size_t scratch_floats, tdx_stream_t stream);
+size_t tdx_conv3x3_train_scratch_floats(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tiles(int B, int H, int W, int cin, int cout);
 int tdx_conv3x3_stat_tile_rows(int B, int H, int W, int cin, int cout);
 /* 1 when (B,H,W,cin,cout) is addressable by the convolution kernels: they use 32-bit buffer

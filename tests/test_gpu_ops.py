@@ -249,6 +249,51 @@ def test_conv3x3_fwd_splitk_inference(tdx, B, H, cin, cout):
     assert rel_err(nchw(out2), ref) < 3e-6
 
 
+@pytest.mark.parametrize("B,H,cin,cout,split", [(256, 4, 512, 512, True), (64, 4, 256, 256, True), (37, 4, 512, 512, True),
+                                                (256, 8, 256, 256, False), (9, 7, 128, 512, True)])
+def test_conv3x3_fwd_train_splitk(tdx, B, H, cin, cout, split):
+    """training convolutions of latency-bound shapes (the UNet bottleneck at the benchmarked batch): K split over
+    64x64 workgroups, then ONE launch reduces the partials in a fixed order, adds the bias and writes the same
+    BatchNorm statistics partials the unsplit epilogue writes.  Also the plain (input-gradient) form."""
+    x, w, b = _conv_inputs(B, H, cin, cout, seed=11)
+    ref = F.conv2d(x, w, b, padding=1)
+    wf, _ = _pack(tdx, w)
+    xin, bd = dev(nhwc(x)), dev(b)
+    need = tdx.lib.tdx_conv3x3_train_scratch_floats(B, H, H, cin, cout)
+    assert (need > 0) == split
+    scratch = torch.full((max(need, 1),), float("nan"), device="cuda")
+    tiles = tdx.lib.tdx_conv3x3_stat_tiles(B, H, H, cin, cout)
+    rows = tdx.lib.tdx_conv3x3_stat_tile_rows(B, H, H, cin, cout)
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, H, H, cout), float("nan"), device="cuda")
+        stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
+        tdx.check(tdx.lib.tdx_conv3x3_fwd_train(xin.data_ptr(), wf.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin,
+                                                cout, 4, stats.data_ptr(), scratch.data_ptr(), need, stream()))
+        outs.append((out, stats))
+    out, stats = outs[0]
+    assert rel_err(nchw(out), ref) < 3e-6
+    assert torch.equal(out, outs[1][0]) and torch.equal(stats, outs[1][1])   # fixed order: reproducible
+    flat = nhwc(ref).reshape(-1, cout).double()
+    for ti in range(tiles):
+        blk = flat[ti * rows:(ti + 1) * rows]
+        assert torch.allclose(stats[ti, 0].double().cpu(), blk.sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.allclose(stats[ti, 1].double().cpu(), (blk - blk.mean(0)).pow(2).sum(0), rtol=1e-4, atol=1e-3)
+    # no statistics, no bias: the form the input gradient uses
+    out0 = torch.full((B, H, H, cout), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd_train(xin.data_ptr(), wf.data_ptr(), None, out0.data_ptr(), B, H, H, cin, cout, 0,
+                                            None, scratch.data_ptr(), need, stream()))
+    assert rel_err(nchw(out0), F.conv2d(x, w, None, padding=1)) < 3e-6
+    # a scratch that is too small uses fewer splits or none
+    small = torch.empty(max(need // 3, 1), device="cuda")
+    out2 = torch.full((B, H, H, cout), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_conv3x3_fwd_train(xin.data_ptr(), wf.data_ptr(), bd.data_ptr(), out2.data_ptr(), B, H, H, cin, cout,
+                                            4, stats.data_ptr(), small.data_ptr(), small.numel(), stream()))
+    assert rel_err(nchw(out2), ref) < 3e-6
+    assert tdx.lib.tdx_conv3x3_fwd_train(xin.data_ptr(), wf.data_ptr(), bd.data_ptr(), out2.data_ptr(), B, H, H, cin, cout,
+                                         2, None, None, 0, stream()) != 0      # BN+ReLU epilogue is not a training flag
+
+
 @pytest.mark.parametrize("B,H,cin,cout", CONV_CASES)
 def test_conv3x3_dgrad_and_wgrad(tdx, B, H, cin, cout):
     x, w, b = _conv_inputs(B, H, cin, cout, seed=2)

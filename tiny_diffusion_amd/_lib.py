@@ -74,6 +74,9 @@ _SIGS = {
     "tdx_conv3x3_fwd_splitk": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, _ptr]),
     "tdx_conv3x3_splitk_scratch_floats": (C.c_size_t, [C.c_int] * 5),
+    "tdx_conv3x3_fwd_train": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        _ptr, _ptr, C.c_size_t, _ptr]),
+    "tdx_conv3x3_train_scratch_floats": (C.c_size_t, [C.c_int] * 5),
     "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_stat_tile_rows": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),

@@ -563,6 +563,70 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
   }
 }
 
+// Training form of the reduction: out = bias + sum_s partial[s] (fixed order) AND the BatchNorm
+// statistics partials the convolution epilogue would have written - per tile of TILE_ROWS pixels and per
+// channel the sum and the sum of squared deviations from the TILE mean - so that bn_finalize sees the
+// same [tiles][2][cout] layout whether K was split or not.  grid (row tiles, cout/64); a thread holds
+// TILE_ROWS/16 rows x 4 columns of the tile in registers for the second (centred) pass.
+template <int TILE_ROWS>
+__global__ void __launch_bounds__(256)
+splitk_reduce_stats_kernel(const float* __restrict__ partial, int splits, int M, int cout,
+                           const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ stats) {
+  constexpr int RJ = TILE_ROWS / 16;
+  __shared__ float red[16][64];
+  __shared__ float tsum[64];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int n0 = blockIdx.y * 64, col = n0 + c4 * 4;
+  const int m0 = blockIdx.x * TILE_ROWS;
+  const int rows_valid = min(TILE_ROWS, M - m0);
+  const size_t slab = (size_t)M * cout;
+  const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[RJ];
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int p = m0 + rg + 16 * j;
+    v[j] = bv;
+    if (p < M) {
+      const float* src = partial + (size_t)p * cout + col;
+      for (int s = 0; s < splits; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(src + s * slab);
+        v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+      }
+      *reinterpret_cast<float4*>(out + (size_t)p * cout + col) = v[j];
+      cs.x += v[j].x; cs.y += v[j].y; cs.z += v[j].z; cs.w += v[j].w;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[rg][c4 * 4]) = cs;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    tsum[threadIdx.x] = t;
+    stats[((size_t)blockIdx.x * 2 + 0) * cout + n0 + threadIdx.x] = t;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)rows_valid;
+  const float4 mean = make_float4(tsum[c4 * 4] * inv_n, tsum[c4 * 4 + 1] * inv_n, tsum[c4 * 4 + 2] * inv_n,
+                                  tsum[c4 * 4 + 3] * inv_n);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < RJ; ++j)
+    if (m0 + rg + 16 * j < M) {
+      const float dx = v[j].x - mean.x, dy = v[j].y - mean.y, dz = v[j].z - mean.z, dw = v[j].w - mean.w;
+      q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    }
+  *reinterpret_cast<float4*>(&red[rg][c4 * 4]) = q;   // everyone read tsum before the barrier below; red is free
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    stats[((size_t)blockIdx.x * 2 + 1) * cout + n0 + threadIdx.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------ dispatch
 struct TileCfg {
   int bm, bn;
@@ -586,6 +650,10 @@ static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 static int g_wgrad_target_big = 1024; // the same for 128x128 tiles (0: g_wgrad_target): at most two of them fit a
                                       // CU (64 KiB of LDS each), so fewer, longer workgroups halve the slab traffic
+static int g_splitk_train = 1;       // training convolutions of latency-bound shapes split K (plan_splitk_train)
+static int g_splitk_train_t64 = 1024;   // ... when the 64x64 grid has fewer tiles than this
+static int g_splitk_train_target = 1536;  // ... into about this many workgroups
+static int g_splitk_train_any = 0;      // 1: also shapes whose picked tile is 128x128
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
@@ -609,6 +677,10 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "splitk_train")) { g_splitk_train = value != 0; return 0; }
+  if (!strcmp(key, "splitk_train_t64")) { g_splitk_train_t64 = value > 0 ? value : 1024; return 0; }
+  if (!strcmp(key, "splitk_train_target")) { g_splitk_train_target = value > 0 ? value : 1536; return 0; }
+  if (!strcmp(key, "splitk_train_any")) { g_splitk_train_any = value != 0; return 0; }
   if (!strcmp(key, "time_proj_early")) { g_tdx_time_proj_early = value != 0; return 0; }
   if (!strcmp(key, "time_stage_diag")) { g_tdx_time_stage = value == 6 ? 6 : 14; return 0; }
   if (!strcmp(key, "time_l1_impl")) { g_tdx_time_l1_impl = value; return 0; }
@@ -719,6 +791,63 @@ extern "C" size_t tdx_conv3x3_splitk_scratch_floats(int B, int H, int W, int cin
   return s > 1 ? (size_t)s * M * cout : 0;
 }
 
+// Split-K plan of the TRAINING convolutions (forward with statistics, input gradient).  At B = 256 the
+// MNIST bottleneck (512 -> 512 at 4x4: 4096 pixels, K = 4608) gets 256 workgroups of 128x64, one per CU,
+// each walking 144 K-tiles whose operands (9.4 MB of weights) miss the L2: 422 us for 19.3 GFLOP, 46 TFLOP/s,
+// a third of what the other layers reach - a lone workgroup has nobody to cover the latency of its next
+// tile.  Such shapes (the picked tile is not 128x128 and the 64x64 grid is under four workgroups per CU) run
+// as 64x64 tiles with K split into ~1536 workgroups, reduced (with the BatchNorm partials) by one more launch.
+static int plan_splitk_train(int64_t M, int cin, int cout, int* kt_per_split, size_t cap_floats = (size_t)-1) {
+  const TileCfg c = pick_tile(M, cout);
+  const int nk = 9 * (cin / BK);
+  *kt_per_split = nk;
+  if (!g_splitk_train || (c.bm == 128 && c.bn == 128 && !g_splitk_train_any) || nk < 24) return 1;
+  const int64_t t64 = ((M + 63) / 64) * (cout / 64);
+  if (t64 >= g_splitk_train_t64) return 1;
+  int s = (int)((g_splitk_train_target + t64 - 1) / t64);
+  if (s > nk / 6) s = nk / 6;
+  const size_t fit = cap_floats / ((size_t)M * cout);
+  if ((size_t)s > fit) s = (int)fit;
+  if (s < 2) return 1;
+  const int per = (nk + s - 1) / s;
+  *kt_per_split = per;
+  return (nk + per - 1) / per;
+}
+
+extern "C" size_t tdx_conv3x3_train_scratch_floats(int B, int H, int W, int cin, int cout) {
+  int per;
+  const int64_t M = (int64_t)B * H * W;
+  const int s = plan_splitk_train(M, cin, cout, &per);
+  return s > 1 ? (size_t)s * M * cout : 0;
+}
+
+// raw-input (LDS-DMA) 64x64 split-K launch, then the training reduction: statistics in tiles of the rows the
+// unsplit kernel would have used (tdx_conv3x3_stat_tile_rows), or the plain sum when stats is null
+static int launch_splitk_train(ConvArgs a, int splits, int per, float* scratch, int stat_rows, hipStream_t st) {
+  float* final_out = a.out;
+  a.out = scratch;
+  a.splits = splits;
+  a.kt_per_split = per;
+  a.tilesN = a.Cout / 64;
+  dim3 grid((cdiv(a.M, 64) + 7) / 8 * 8 * a.tilesN, splits);
+  conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
+  TDX_CHECK_LAUNCH();
+  if (a.stats) {
+    dim3 rg(cdiv(a.M, stat_rows), a.Cout / 64);
+    if (stat_rows == 128)
+      splitk_reduce_stats_kernel<128><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats);
+    else
+      splitk_reduce_stats_kernel<64><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats);
+  } else {
+    const int64_t n4 = (int64_t)a.M * a.Cout / 4;
+    int rg = (int)((n4 + 255) / 256);
+    if (rg > 2048) rg = 2048;
+    splitk_reduce_kernel<false><<<rg, 256, 0, st>>>(scratch, splits, n4, a.Cout, a.bias, nullptr, nullptr, final_out);
+  }
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int EPI_>
 static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scratch, hipStream_t st) {
   float* final_out = a.out;
@@ -775,7 +904,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
                             const float* in_scale, const float* in_shift,
                             const float* out_scale, const float* out_shift,
                             float* stats_partial, float* splitk_scratch, size_t scratch_floats,
-                            tdx_stream_t stream) {
+                            tdx_stream_t stream, bool train = false) {
   if (!in || !wpk || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   if (cin % BK || cout % 64) return TDX_E_SHAPE;
   if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
@@ -807,7 +936,11 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   if (g_conv_stamp == 2 && stats_partial && g_tdx_diag_buffer && slot < 16)
     a.stamps = reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) + (size_t)(slot++) * 8 * 8192;
   hipStream_t st = to_stream(stream);
-  if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
+  if (train && splitk_scratch && !(flags & (TDX_CONV_IN_BNRELU | TDX_CONV_OUT_BNRELU)) && g_conv_dma) {
+    int per;
+    const int splits = plan_splitk_train(M64, cin, cout, &per, scratch_floats);
+    if (splits > 1) return launch_splitk_train(a, splits, per, splitk_scratch, c.bm, st);
+  } else if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
     int per;
     const int splits = plan_splitk(M64, cin, cout, &per, scratch_floats);
     if (splits > 1) {
@@ -828,6 +961,14 @@ extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* b
                                float* stats_partial, tdx_stream_t stream) {
   return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, in_scale, in_shift, out_scale,
                           out_shift, stats_partial, nullptr, 0, stream);
+}
+
+extern "C" int tdx_conv3x3_fwd_train(const float* in, const float* wpk, const float* bias, float* out, int B,
+                                     int H, int W, int cin, int cout, int flags, float* stats_partial,
+                                     float* scratch, size_t scratch_floats, tdx_stream_t stream) {
+  if (flags & ~TDX_CONV_OUT_STATS) return TDX_E_BADARG;
+  return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr,
+                          stats_partial, scratch, scratch_floats, stream, true);
 }
 
 extern "C" int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias, float* out,

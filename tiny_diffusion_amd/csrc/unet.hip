@@ -98,6 +98,7 @@ struct Layout {
   size_t A[13];                 // relu(bn(Y[u])) for the units whose successor is a 3x3 conv on it (else unused)
   size_t ep[3], cat[3], d1a;    // pooled encoder outputs, decoder inputs (cat[0] = level 3), resized d1
   size_t stats;                 // conv epilogue partials (largest unit)
+  size_t ksplit, ksplit_floats; // split-K partials of the training convolutions (forward and dgrad share it: main stream)
   // backward
   size_t G1, G2, G3, G4, GS[3], gtp[3], slabs, slabs2, bnscr, smallp, smallp2, timescr;
   size_t gbuf;                  // floats in EACH of G1..G4
@@ -114,7 +115,7 @@ Layout make_layout(const NetSpec& S, int B) {
   L.sin = take(b * S.time_dim); L.pre = take(b * S.time_dim); L.emb = take(b * S.time_dim);
   for (int k = 0; k < 3; ++k) L.tp[k] = take(b * S.skip_ch[k]);
   L.x0 = take(b * px0 * S.x0_ch);
-  size_t stats = 0, slabs = 0, bnscr = 0, gbuf = 0;
+  size_t stats = 0, slabs = 0, bnscr = 0, gbuf = 0, ksplit = 0;
   for (int u = 0; u < 13; ++u) {
     const UnitDef& d = S.units[u];
     L.Y[u] = take(b * d.hw * d.hw * d.cout);
@@ -123,6 +124,8 @@ Layout make_layout(const NetSpec& S, int B) {
     stats = std::max(stats, (size_t)tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout) * 2 * d.cout);
     slabs = std::max(slabs, (size_t)tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout) * 9 *
                                 (size_t)d.cin * d.cout);
+    ksplit = std::max(ksplit, std::max(tdx_conv3x3_train_scratch_floats(B, d.hw, d.hw, d.cin, d.cout),
+                                       tdx_conv3x3_train_scratch_floats(B, d.hw, d.hw, d.cout, d.cin)));
     bnscr = std::max(bnscr, tdx_bn_relu_bwd_scratch_floats((int64_t)b * d.hw * d.hw, d.cout));
     gbuf = std::max(gbuf, b * d.hw * d.hw * (size_t)std::max(d.cin, d.cout));
   }
@@ -137,6 +140,8 @@ Layout make_layout(const NetSpec& S, int B) {
   L.d1a = take(b * S.out_hw * S.out_hw * 64);
   gbuf = std::max(gbuf, b * (size_t)S.out_hw * S.out_hw * 64);
   L.stats = take(stats);
+  L.ksplit_floats = ksplit;
+  L.ksplit = take(ksplit);
   L.gbuf = gbuf;
   L.G1 = take(gbuf); L.G2 = take(gbuf); L.G3 = take(gbuf); L.G4 = take(gbuf);
   for (int k = 0; k < 3; ++k) {
@@ -601,9 +606,12 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const bool bn_on_load = d.in_bn && !u->materialize;
     if (d.in_bn && u->materialize) in = ws + L.A[i - 1];
     int flags = (bn_on_load ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
-    RC(tdx_conv3x3_fwd(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, flags,
-                       bn_on_load ? sc(i - 1) : nullptr, bn_on_load ? sh(i - 1) : nullptr, nullptr, nullptr,
-                       ws + L.stats, stream));
+    if (bn_on_load)
+      RC(tdx_conv3x3_fwd(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, flags, sc(i - 1), sh(i - 1), nullptr, nullptr,
+                         ws + L.stats, stream));
+    else  // raw input: shapes that would put one lone workgroup on a CU split K (tdx_conv3x3_fwd_train)
+      RC(tdx_conv3x3_fwd_train(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, flags, ws + L.stats, ws + L.ksplit,
+                               L.ksplit_floats, stream));
     const int tiles = tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout);
     RC(finalize_bn(i, tiles, tdx_conv3x3_stat_tile_rows(B, d.hw, d.hw, d.cin, d.cout), (int64_t)B * d.hw * d.hw));
     if (u->materialize && i + 1 < 13 && S.units[i + 1].in_bn)
@@ -789,8 +797,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       RC(tdx_conv3x3_fwd_bf16(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
                               nullptr, nullptr, nullptr, nullptr, stream));
     else
-      RC(tdx_conv3x3_fwd(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+      RC(tdx_conv3x3_fwd_train(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
+                               ws + L.ksplit, L.ksplit_floats, stream));
     *g_in_out = g_in;
     return 0;
   };

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Timeline of ONE training step from a rocprofv3 kernel trace of `python3 bench.py --train-only`:
+
+    python tools/step_timeline.py <..._kernel_trace.csv> [step index, default 10] > profiles/rNN_step_timeline.txt
+
+One line per kernel: start / end / duration in us relative to the end of the previous step's Adam kernel, the
+hardware queue (1 = main stream, 2 = weight-gradient stream, 3 = helper stream), C for the MFMA convolutions,
+the kernel name and its grid.  The footer sums the convolution kernels by role and lists every interval with no
+convolution in flight (what the step pays on top of its GEMMs)."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam") or "adam_clip_kernel" in r["Kernel_Name"]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+a, b = adam[k], adam[k + 1]
+seg = rows[a + 1:b + 1]
+t0 = int(rows[a]["End_Timestamp"])
+queues = {}
+
+
+def short(n):
+    return n.replace("void ", "").split("(")[0][:52]
+
+
+def isconv(n):
+    return "conv3x3_igemm" in n or "conv3x3_wgrad" in n or "conv3x3_bf16" in n
+
+
+iv = []
+for r in seg:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    q = queues.setdefault(r["Queue_Id"], len(queues) + 1)
+    n = r["Kernel_Name"]
+    if isconv(n):
+        iv.append((s, e, n))
+    print(f"{s / 1e3:9.1f} {e / 1e3:9.1f} {(e - s) / 1e3:8.1f}  q{q} {'C' if isconv(n) else ' '} {short(n):52s} "
+          f"grid {int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)}x{r['Grid_Size_Y']}")
+end = int(seg[-1]["End_Timestamp"]) - t0
+print(f"\nstep wall {end / 1e3:.1f} us, {len(seg)} kernels")
+for tag, pred in (("forward/dgrad (igemm)", lambda n: "igemm" in n or "conv3x3_bf16_kernel" in n),
+                  ("wgrad", lambda n: "wgrad" in n)):
+    print(f"  sum of {tag} kernels: {sum(e - s for s, e, n in iv if pred(n)) / 1e3:.1f} us")
+gaps, cur = [], 0
+for s, e, _ in sorted(iv):
+    if s > cur:
+        gaps.append((cur, s))
+    cur = max(cur, e)
+if cur < end:
+    gaps.append((cur, end))
+print(f"  no convolution in flight: {sum(e - s for s, e in gaps) / 1e3:.1f} us in {len(gaps)} intervals; the longest:")
+for s, e in sorted(gaps, key=lambda g: g[0] - g[1])[:12]:
+    inside = [short(r["Kernel_Name"]) for r in seg
+              if int(r["Start_Timestamp"]) - t0 < e and int(r["End_Timestamp"]) - t0 > s and not isconv(r["Kernel_Name"])]
+    print(f"    {s / 1e3:9.1f} .. {e / 1e3:9.1f} ({(e - s) / 1e3:6.1f} us): {', '.join(dict.fromkeys(inside))}")
