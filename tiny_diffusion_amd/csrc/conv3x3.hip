@@ -650,6 +650,10 @@ static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 static int g_wgrad_target_big = 1024; // the same for 128x128 tiles (0: g_wgrad_target): at most two of them fit a
                                       // CU (64 KiB of LDS each), so fewer, longer workgroups halve the slab traffic
+static int g_splitk_fused = 0;       // 1: the last-arriving workgroup of a tile reduces the split-K partials (conv_epilogue).
+                                      // OFF: the device-scope release/acquire it needs (splits of a tile sit behind
+                                      // different XCDs' L2s: buffer_wbl2 / buffer_inv) costs ~68 us per convolution,
+                                      // the launch it saves ~5 - measured n=16 reverse step 0.527 -> 1.275 ms
 static int g_splitk_train = 1;       // training convolutions of latency-bound shapes split K (plan_splitk_train)
 static int g_splitk_train_t64 = 1024;   // ... when the 64x64 grid has fewer tiles than this
 static int g_splitk_train_target = 1536;  // ... into about this many workgroups
@@ -677,6 +681,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "splitk_fused")) { g_splitk_fused = value != 0; return 0; }
   if (!strcmp(key, "splitk_train")) { g_splitk_train = value != 0; return 0; }
   if (!strcmp(key, "splitk_train_t64")) { g_splitk_train_t64 = value > 0 ? value : 1024; return 0; }
   if (!strcmp(key, "splitk_train_target")) { g_splitk_train_target = value > 0 ? value : 1536; return 0; }
@@ -849,13 +854,24 @@ static int launch_splitk_train(ConvArgs a, int splits, int per, float* scratch, 
 }
 
 template <int EPI_>
-static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scratch, hipStream_t st) {
+static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scratch, hipStream_t st,
+                         unsigned* counters = nullptr, int n_counters = 0) {
   float* final_out = a.out;
   a.out = scratch;
   a.splits = splits;
   a.kt_per_split = per;
   const size_t lds = (size_t)2 * (64 + 64) * BKP * sizeof(float);
   dim3 grid((cdiv(a.M, 64) + 7) / 8 * 8 * a.tilesN, splits);
+  if (counters && g_splitk_fused && !in_bn && g_conv_dma && cdiv(a.M, 64) * a.tilesN <= n_counters) {
+    // one launch: the last workgroup of every tile reduces (conv_epilogue); ~5 us per convolution of a
+    // reverse step, where a kernel boundary costs as much as a small kernel
+    a.tile_counters = counters;
+    a.final_out = final_out;
+    if (EPI_ != EPI_BNRELU) a.out_scale = a.out_shift = nullptr;
+    conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
+    TDX_CHECK_LAUNCH();
+    return 0;
+  }
   if (in_bn) conv3x3_igemm2_kernel<64, 64, true, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
   else if (g_conv_dma)
     conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
@@ -904,7 +920,8 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
                             const float* in_scale, const float* in_shift,
                             const float* out_scale, const float* out_shift,
                             float* stats_partial, float* splitk_scratch, size_t scratch_floats,
-                            tdx_stream_t stream, bool train = false) {
+                            tdx_stream_t stream, bool train = false, unsigned* counters = nullptr,
+                            int n_counters = 0) {
   if (!in || !wpk || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   if (cin % BK || cout % 64) return TDX_E_SHAPE;
   if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
@@ -914,7 +931,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   int64_t M64 = (int64_t)B * H * W;
   if (M64 >= (1ll << 31)) return TDX_E_SHAPE;
   if (!descriptor_fits(M64, cin, W + 1) || (int64_t)cout * 9 * cin * 4 >= (1ll << 31)) return TDX_E_SHAPE;
-  ConvArgs a;
+  ConvArgs a{};
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
   a.stats = stats_partial;
@@ -945,8 +962,9 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
     const int splits = plan_splitk(M64, cin, cout, &per, scratch_floats);
     if (splits > 1) {
       const bool in_bn = flags & TDX_CONV_IN_BNRELU;
-      if (flags & TDX_CONV_OUT_BNRELU) return launch_splitk<EPI_BNRELU>(a, in_bn, splits, per, splitk_scratch, st);
-      return launch_splitk<EPI_PLAIN>(a, in_bn, splits, per, splitk_scratch, st);
+      if (flags & TDX_CONV_OUT_BNRELU)
+        return launch_splitk<EPI_BNRELU>(a, in_bn, splits, per, splitk_scratch, st, counters, n_counters);
+      return launch_splitk<EPI_PLAIN>(a, in_bn, splits, per, splitk_scratch, st, counters, n_counters);
     }
   }
   if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128>(a, flags, st);
@@ -961,6 +979,17 @@ extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* b
                                float* stats_partial, tdx_stream_t stream) {
   return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, in_scale, in_shift, out_scale,
                           out_shift, stats_partial, nullptr, 0, stream);
+}
+
+// tdx_conv3x3_fwd_splitk with the reduction folded into the convolution: `counters` = n_counters zeroed
+// unsigned ints owned by the caller for this purpose (the kernel leaves them zeroed)
+int tdx_conv3x3_fwd_splitk_fused(const float* in, const float* wpk, const float* bias, float* out, int B, int H,
+                                 int W, int cin, int cout, int flags, const float* out_scale,
+                                 const float* out_shift, float* scratch, size_t scratch_floats, unsigned* counters,
+                                 int n_counters, tdx_stream_t stream) {
+  if (!scratch) return TDX_E_BADARG;
+  return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, nullptr, nullptr, out_scale, out_shift,
+                          nullptr, scratch, scratch_floats, stream, false, counters, n_counters);
 }
 
 extern "C" int tdx_conv3x3_fwd_train(const float* in, const float* wpk, const float* bias, float* out, int B,

@@ -473,7 +473,7 @@ extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const
   if ((flags & TDX_CONV_OUT_STATS) && !stats_partial) return TDX_E_BADARG;
   if ((flags & TDX_CONV_OUT_STATS) && (flags & TDX_CONV_OUT_BNRELU)) return TDX_E_BADARG;
   if (!tdx_conv3x3_shape_ok(B, H, W, cin, cout)) return TDX_E_SHAPE;
-  ConvArgs a;
+  ConvArgs a{};
   a.in = in; a.w = static_cast<const float*>(wpk_bf16); a.bias = bias; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
   a.stats = stats_partial;

@@ -20,6 +20,11 @@ struct ConvArgs {
   int splits, kt_per_split;  // split-K (variant 2): blockIdx.y = split, raw partials to `out`
   int dbg;                   // timing experiments only (tdx_tune_set "conv_dbg"): 1 no barrier,
                              // 2 no LDS stores, 4 no global loads in the main loop -> WRONG results
+  // split-K with the reduction folded in (inference): workgroups of one tile count themselves in
+  // tile_counters[tile]; the LAST one to arrive sums all `splits` partials in the fixed order 0..splits-1,
+  // applies bias / BN+ReLU (out_scale) and writes final_out; null = a separate launch reduces
+  unsigned* tile_counters;
+  float* final_out;
   unsigned long long* stamps;  // diagnostics (tools/gpu_clock_probe.py): per workgroup {shader cycles, 100 MHz ticks}
                                // around the main loop; null in every product launch
 };
@@ -50,6 +55,49 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
           const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (p < a.M) part[(size_t)p * a.Cout + col] = acc[im][in][r];
         }
+    }
+    if (!a.tile_counters) return;
+    // ---- last-arriver reduction.  Release: every thread's partials are visible device-wide (the splits of a
+    // tile may run on different XCDs, i.e. behind different L2s) before thread 0 counts this workgroup in;
+    // acquire on the other side before the partials are read.  Nobody WAITS for anybody: a workgroup that is
+    // not the last one simply leaves, so the scheme cannot deadlock whatever the dispatch order.
+    __threadfence();
+    __syncthreads();   // also: every wave has left the K loop, the tile buffers are free
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);
+    const int tile = tile_m * a.tilesN + (n0 / BN);
+    if (tid == 0) {
+      const unsigned old = atomicAdd(a.tile_counters + tile, 1u);
+      flag[0] = (old == (unsigned)a.splits - 1u);
+      if (old == (unsigned)a.splits - 1u) a.tile_counters[tile] = 0u;   // ready for the next launch
+    }
+    __syncthreads();
+    if (!flag[0]) return;
+    __threadfence();
+    constexpr int C4 = BN / 4, RG = 256 / C4;
+    const int c4 = tid % C4, rg = tid / C4;
+    const int col = n0 + c4 * 4;
+    const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.out_scale) {
+      sc = *reinterpret_cast<const float4*>(a.out_scale + col);
+      sh = *reinterpret_cast<const float4*>(a.out_shift + col);
+    }
+    const size_t slab = (size_t)a.M * a.Cout;
+#pragma unroll
+    for (int j = 0; j < BM / RG; ++j) {
+      const int p = m0 + rg + RG * j;
+      if (p >= a.M) continue;
+      const float* src = a.out + (size_t)p * a.Cout + col;
+      float4 v = bv;
+      for (int s2 = 0; s2 < a.splits; ++s2) {
+        const float4 t = *reinterpret_cast<const float4*>(src + s2 * slab);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (a.out_scale) {
+        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+      }
+      *reinterpret_cast<float4*>(a.final_out + (size_t)p * a.Cout + col) = v;
     }
     return;
   }

@@ -31,6 +31,10 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
 // one projection's share of the above (time_embed.hip); then tdx_time_embed_bwd(..., proj_done = true)
 int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
                       const float* g_tk, float* scratch, int B, hipStream_t st, int td = 0);
+int tdx_conv3x3_fwd_splitk_fused(const float* in, const float* wpk, const float* bias, float* out, int B, int H,
+                                 int W, int cin, int cout, int flags, const float* out_scale,
+                                 const float* out_shift, float* scratch, size_t scratch_floats, unsigned* counters,
+                                 int n_counters, tdx_stream_t stream);
 #define TDX_PACK_MAX 13
 struct TdxPackBatch {
   const float* w[TDX_PACK_MAX];

@@ -62,6 +62,7 @@ const NetSpec SPECS[2] = {
       {64, 64, 32, 1, 64}}}};
 
 constexpr int N_STAGES = 15;
+constexpr int TDX_KCOUNT = 1024;
 
 // The table rows are the reference resolutions.  The LAION network is fully convolutional
 // (floor-mode pooling, exact 2x up-sampling, skips at equal resolution:
@@ -173,6 +174,7 @@ struct tdx_unet {
   float* wpack;            // device: per unit fwd pack then dgrad pack
   size_t wf_off[13], wd_off[13];
   float* infer_ss;         // device: per unit scale|shift from running stats (INFER mode)
+  unsigned* kcount;        // device: TDX_KCOUNT zeroed tile counters of the fused split-K reduction (INFER mode)
   size_t iss_off[13];
   bool packed;
   int precision, saved_precision;  // TDX_PREC_*: of the next forward / of the saved forward
@@ -248,6 +250,9 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   if (e != hipSuccess) { delete u; return (int)e; }
   e = hipMalloc(&u->infer_ss, so * sizeof(float));
   if (e != hipSuccess) { (void)hipFree(u->wpack); delete u; return (int)e; }
+  e = hipMalloc(&u->kcount, TDX_KCOUNT * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(u->kcount, 0, TDX_KCOUNT * sizeof(unsigned));
+  if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); (void)hipFree(u->kcount); delete u; return (int)e; }
   u->packed = false;
   u->precision = TDX_PREC_F32;
   u->saved_precision = TDX_PREC_F32;
@@ -262,7 +267,7 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   u->materialize = g_tdx_materialize != 0;
   u->use_streams = g_tdx_streams < 0 ? (u->spec ? u->spec->overlap : 0) : g_tdx_streams;
   e = hipStreamCreateWithPriority(&u->side_own, hipStreamNonBlocking, lo);
-  if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); delete u; return (int)e; }
+  if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); (void)hipFree(u->kcount); delete u; return (int)e; }
   for (int i = 0; i < 13; ++i) {
     (void)hipEventCreateWithFlags(&u->ev_dy[i], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&u->ev_w[i], hipEventDisableTiming);
@@ -281,6 +286,7 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
     (void)hipStreamDestroy(u->side_own);
     (void)hipFree(u->wpack);
     (void)hipFree(u->infer_ss);
+    (void)hipFree(u->kcount);
     delete u;
     return (int)e;
   }
@@ -344,6 +350,7 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
   (void)hipStreamDestroy(u->side_own);
   (void)hipFree(u->wpack);
   (void)hipFree(u->infer_ss);
+  (void)hipFree(u->kcount);
   delete u;
   return 0;
 }
@@ -600,8 +607,8 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       const float* iss = u->infer_ss + u->iss_off[i];
       // small-batch sampling is latency-bound: split K over more workgroups where the tile
       // grid would not fill the chip; the (unused in INFER mode) gradient buffers are the scratch
-      return tdx_conv3x3_fwd_splitk(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU,
-                                    nullptr, nullptr, iss, iss + d.cout, ws + L.G1, 2 * L.gbuf, stream);
+      return tdx_conv3x3_fwd_splitk_fused(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, iss,
+                                          iss + d.cout, ws + L.G1, 2 * L.gbuf, u->kcount, TDX_KCOUNT, stream);
     }
     const bool bn_on_load = d.in_bn && !u->materialize;
     if (d.in_bn && u->materialize) in = ws + L.A[i - 1];
