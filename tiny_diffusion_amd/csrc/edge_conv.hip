@@ -1,0 +1,439 @@
+// The two boundary convolutions of the UNet - initial_conv (model input, 1 | 4 channels, NCHW ->
+// 64 channels-last) and final_conv (64 channels-last -> 1 | 4 channels NCHW) - and their backward
+// passes (diffusion.py:28, 98, 116, 160; conditional_diffusion_laion.py:244, 296).  One side of each
+// is THIN (K = 9 or 36 taps x channels), the other is a 256-byte-per-pixel activation: all five are
+// HBM-bound on the fat tensor (67 MB at B = 256, 32x32) and none is a job for the implicit-GEMM
+// kernel (padding 4 channels to 32 would multiply its work by eight).  They are small GEMMs all the
+// same, so the three kernels below run them on the fp32 MFMA (exact fp32 products, fp32 accumulate:
+// the same arithmetic as the CUDA-core loops they replace, up to summation order) with the thin
+// operand gathered straight from the (L2-resident) NCHW tensor:
+//   thin_to_fat_conv   out[p][c] = b[c] + sum_k T[p][k] W[k][c]      initial_conv forward; final_conv dgrad (taps mirrored)
+//   fat_to_thin_conv   out[n][o][p] = b[o] + sum_{tap,c} F[p+tap][c] W[o][c][tap]      final_conv forward (VALU, weights in registers)
+//   thin_fat_wgrad     dW[k][c] = sum_p T[p][k] F[p][c]              both weight gradients (+ bias gradients)
+// T[p][k = (ch, tap)] = thin[n][ch][pixel p shifted by the tap] (0 outside the image).
+// Before (B = 256, LAION 4x32x32, us): 107 / 142 / 54 / 408 / 382 of a 10.1 ms step, mostly exposed at its head and tail.
+#include "internal.h"
+
+#define IC_CO 64
+#define SMALLP_W 2368  // floats per row of the weight-gradient partial buffer (4*64*9 + 64)
+
+namespace {
+
+// k -> (thin channel, dy, dx) for k < K, by multiplications (k < 64)
+__device__ __forceinline__ void tap_of(int k, int& c, int& dy, int& dx) {
+  c = (k * 57) >> 9;          // k / 9
+  const int tap = k - 9 * c;
+  const int ty = (tap * 11) >> 5;  // tap / 3
+  dy = ty - 1;
+  dx = tap - 3 * ty - 1;
+}
+
+// ------------------------------------------------------------------ thin -> fat
+// 128 pixels x 64 channels per workgroup pass; wave = 32 pixels x 64 channels = two 32x32 MFMA
+// tiles, K = CT*9 in steps of 2.  FLIP = false: w is [cor][CT][9] (initial_conv.weight), channels
+// >= cor are written as zeros; FLIP = true: w is [CT][64][9] (final_conv.weight), the input
+// gradient: g_in[p][c] = sum_{o,tap} g_out[n][o][p - tap] W[o][c][tap].
+template <int CT, bool FLIP>
+__global__ void __launch_bounds__(256)
+thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict__ w,
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W,
+                        int cor) {
+  constexpr int K = CT * 9, KS = (K + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
+
+  float bfr[2][KS], bv[2];
+  int koff[KS], kdy[KS], kdx[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + half;
+    int c, dy, dx;
+    tap_of(k, c, dy, dx);
+    if (FLIP) { dy = -dy; dx = -dx; }
+    kdy[s] = k < K ? dy : 2 * H;  // k >= K (odd K padding): never valid
+    kdx[s] = dx;
+    koff[s] = c * HW + dy * W + dx;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = cb * 32 + l31;
+      float v = 0.f;
+      if (k < K) {
+        if (!FLIP) {
+          if (col < cor) v = w[col * K + k];
+        } else {
+          const int tap = k - 9 * c;
+          v = w[(c * IC_CO + col) * 9 + tap];
+        }
+      }
+      bfr[cb][s] = v;
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) bv[cb] = (!FLIP && bias && cb * 32 + l31 < cor) ? bias[cb * 32 + l31] : 0.f;
+
+  const int64_t tiles = (M + 127) / 128;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t pw0 = tile * 128 + wave * 32;
+    const int64_t p = pw0 + l31;
+    const bool pv = p < M;
+    const int n = pv ? (int)(p / HW) : 0;
+    const int r = pv ? (int)(p - (int64_t)n * HW) : 0;
+    const int oh = r / W, ow = r - oh * W;
+    const float* base = thin + (int64_t)n * CT * HW + r;
+    float a[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bool ok = pv && (unsigned)(oh + kdy[s]) < (unsigned)H && (unsigned)(ow + kdx[s]) < (unsigned)W;
+      a[s] = ok ? base[koff[s]] : 0.f;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = bv[cb];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bfr[0][s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bfr[1][s], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t pp = pw0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (pp < M) {
+        out[pp * IC_CO + l31] = acc[0][i];
+        out[pp * IC_CO + 32 + l31] = acc[1][i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fat -> thin
+// out[n][o][p] = b[o] + sum_tap sum_c in[p+tap][c] * W[o][c][tap]; 16 lanes per pixel, each with four
+// channels of the pixel and ITS weights (CO x 9 x 4) in registers; shuffle-reduced over the 16 lanes.
+template <int CO>
+__global__ void __launch_bounds__(256)
+fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+  const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
+  const int64_t Mpad = (M + 15) / 16 * 16;
+  float4 wr[CO][9];
+  float bv[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    bv[co] = bias[co];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* q = w + (co * IC_CO + ci) * 9 + tap;  // w is [co][c][tap]
+      wr[co][tap] = make_float4(q[0], q[9], q[18], q[27]);
+    }
+  }
+  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
+    float s[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) s[co] = 0.f;
+    int n = 0, r = 0;
+    if (p < M) {
+      n = (int)(p / HW);
+      r = (int)(p - (int64_t)n * HW);
+      const int oh = r / W, ow = r - oh * W;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4*>(
+              in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            s[co] = fmaf(v.x, wr[co][tap].x, s[co]);
+            s[co] = fmaf(v.y, wr[co][tap].y, s[co]);
+            s[co] = fmaf(v.z, wr[co][tap].z, s[co]);
+            s[co] = fmaf(v.w, wr[co][tap].w, s[co]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      s[co] += __shfl_xor(s[co], 8, 64);
+      s[co] += __shfl_xor(s[co], 4, 64);
+      s[co] += __shfl_xor(s[co], 2, 64);
+      s[co] += __shfl_xor(s[co], 1, 64);
+    }
+    if ((threadIdx.x & 15) == 0 && p < M) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) out[((int64_t)n * CO + co) * HW + r] = s[co] + bv[co];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight gradients
+// MFMA rows = the 64 fat channels (two tiles), columns = k (one tile for K <= 32, two otherwise),
+// reduction over pixels two at a time.  A workgroup takes `pix` consecutive pixels, a wave a quarter
+// of them; the four waves' accumulators are summed through LDS in wave order (deterministic) and the
+// workgroup writes ONE row of the partial buffer, in the parameter's own [o][c][tap] order, that
+// reduce_partials sums over workgroups in a fixed order.
+//   FLIP = false  initial_conv: thin = x, fat = g(x0); dW[o][c][tap] at o*K + (c*9+tap), o < cor;
+//                 an extra all-ones column gives db[o] = sum_p g[p][o] at cor*K + o
+//   FLIP = true   final_conv: thin = g_out, fat = the conv's input; dW[o][c][tap] at (o*64 + c)*9 + tap;
+//                 db[o] = sum_p g_out[n][o][p] = the column sums of the centre taps, at CT*576 + o
+template <int CT, bool FLIP>
+__global__ void __launch_bounds__(256)
+thin_fat_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ fat,
+                      float* __restrict__ partial, int B, int H, int W, int pix, int cor) {
+  constexpr int K = CT * 9, KC = FLIP ? K : K + 1, CB = KC <= 32 ? 1 : 2;
+  __shared__ float red[IC_CO][CB * 32 + 1];
+  __shared__ float dbl[CB * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HW = H * W;
+  const int64_t M = (int64_t)B * HW;
+  const int per_wave = pix / 4;
+  const int64_t p0 = (int64_t)blockIdx.x * pix + (int64_t)wave * per_wave;
+  const int64_t p1 = min(p0 + per_wave, M);
+
+  int kind[CB], koff[CB], kdy[CB], kdx[CB];  // kind: 0 tap, 1 ones, 2 padding, 3 centre tap (FLIP: feeds db)
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int k = cb * 32 + l31;
+    int c, dy, dx;
+    tap_of(k < K ? k : 0, c, dy, dx);
+    if (FLIP) { dy = -dy; dx = -dx; }
+    kind[cb] = k < K ? ((FLIP && dy == 0 && dx == 0) ? 3 : 0) : (k == K && !FLIP) ? 1 : 2;
+    kdy[cb] = dy; kdx[cb] = dx;
+    koff[cb] = c * HW + dy * W + dx;
+  }
+  f32x16 acc[2][CB];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+  float dbacc[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) dbacc[cb] = 0.f;
+
+  // this lane's pixel of the current pair: q = p + half, walked two at a time (W >= 4)
+  int64_t q = p0 + half;
+  int n = 0, oh = 0, ow = 0;
+  if (q < M) {
+    n = (int)(q / HW);
+    const int r = (int)(q - (int64_t)n * HW);
+    oh = r / W;
+    ow = r - oh * W;
+  }
+#pragma unroll 4
+  for (int64_t p = p0; p < p1; p += 2, q += 2) {
+    const bool qv = q < p1;
+    const float* frow = fat + q * IC_CO + l31;
+    const float a0 = qv ? frow[0] : 0.f;
+    const float a1 = qv ? frow[32] : 0.f;
+    const float* tb = thin + (int64_t)n * CT * HW + oh * W + ow;
+    float bq[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      float v = 0.f;
+      if (kind[cb] == 1) v = qv ? 1.f : 0.f;
+      else if (kind[cb] != 2) {
+        const bool ok = qv && (unsigned)(oh + kdy[cb]) < (unsigned)H && (unsigned)(ow + kdx[cb]) < (unsigned)W;
+        v = ok ? tb[koff[cb]] : 0.f;
+        if (FLIP && kind[cb] == 3) dbacc[cb] += v;
+      }
+      bq[cb] = v;
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[cb], acc[0][cb], 0, 0, 0);
+      acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[cb], acc[1][cb], 0, 0, 0);
+    }
+    ow += 2;
+    if (ow >= W) { ow -= W; if (++oh == H) { oh = 0; ++n; } }
+  }
+
+  // waves add their tiles in wave order
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            float* d = &red[row][cb * 32 + l31];
+            *d = wv == 0 ? acc[rb][cb][i] : *d + acc[rb][cb][i];
+          }
+      if (FLIP) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const float v = dbacc[cb] + __shfl_xor(dbacc[cb], 32, 64);
+          if (half == 0) dbl[cb * 32 + l31] = wv == 0 ? v : dbl[cb * 32 + l31] + v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* prow = partial + (size_t)blockIdx.x * SMALLP_W;
+  for (int i = threadIdx.x; i < IC_CO * K; i += 256) {
+    const int row = i / K, k = i - row * K;
+    if (!FLIP) {
+      if (row < cor) prow[row * K + k] = red[row][k];
+    } else {
+      const int o = k / 9, tap = k - 9 * o;
+      prow[(o * IC_CO + row) * 9 + tap] = red[row][k];
+    }
+  }
+  if (!FLIP) {
+    if (threadIdx.x < cor) prow[cor * K + threadIdx.x] = red[threadIdx.x][K];
+  } else if (threadIdx.x < CT) {
+    prow[CT * 576 + threadIdx.x] = dbl[threadIdx.x * 9 + 4];
+  }
+}
+
+// out[i] = sum_b partial[b*stride + i], i < count.  Fixed summation order (deterministic),
+// double accumulation; block = 32 columns x 8 interleaved row slices.  Columns >= split go to out2
+// (the bias gradient behind the weight gradient in one partial row).
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, float* __restrict__ out2,
+                       int split, int nblk, int stride, int count) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (i < count) {
+#pragma unroll 4
+    for (int b = sl; b < nblk; b += 8) s += (double)partial[(size_t)b * stride + i];
+  }
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    if (i < split) out[i] = (float)t;
+    else out2[i - split] = (float)t;
+  }
+}
+
+// First level of a long reduction, IN PLACE: block (c, g) sums the rows congruent to g modulo
+// gridDim.y over its 32 columns and stores the sum into row g.  No block reads what another one
+// writes (rows of another residue class, or other columns), and a block has read all of its rows
+// before it writes (barrier), so nblk rows become gridDim.y rows with no second buffer.
+__global__ void __launch_bounds__(256)
+fold_partials_kernel(float* __restrict__ partial, int nblk, int stride, int count) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cl, g = blockIdx.y, G = gridDim.y;
+  double s = 0.0;
+  if (i < count) {
+#pragma unroll 4
+    for (int b = g + sl * G; b < nblk; b += 8 * G) s += (double)partial[(size_t)b * stride + i];
+  }
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    partial[(size_t)g * stride + i] = (float)t;
+  }
+}
+
+constexpr int FOLD_ROWS = 32;
+
+// out[0..split) and out2[0..count-split) from the columns of `partial` (which is consumed)
+int reduce_partials2(float* partial, float* out, float* out2, int split, int nblk, int stride, int count,
+                     hipStream_t st) {
+  if (nblk > 4 * FOLD_ROWS) {
+    fold_partials_kernel<<<dim3(cdiv(count, 32), FOLD_ROWS), 256, 0, st>>>(partial, nblk, stride, count);
+    TDX_CHECK_LAUNCH();
+    nblk = FOLD_ROWS;
+  }
+  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, out2, split, nblk, stride, count);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+constexpr int WGRAD_PIX = 512;  // pixels per workgroup of thin_fat_wgrad_kernel (a multiple of 8)
+
+int conv_grid(int64_t M) {
+  const int64_t tiles = (M + 127) / 128;
+  return (int)std::min<int64_t>(tiles, 4096);
+}
+
+}  // namespace
+
+int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
+                        hipStream_t st) {
+  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, nullptr, count, nblk, stride, count);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
+                         int W, int cin, int cout_real, hipStream_t st) {
+  const int grid = conv_grid((int64_t)B * H * W);
+  if (cin == 1 && cout_real == 64)
+    thin_to_fat_conv_kernel<1, false><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W, cout_real);
+  else if (cin == 4 && cout_real == 32)
+    thin_to_fat_conv_kernel<4, false><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W, cout_real);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
+                         int cout, hipStream_t st) {
+  const int grid = conv_grid((int64_t)B * H * W);
+  if (cout == 1) thin_to_fat_conv_kernel<1, true><<<grid, 256, 0, st>>>(g_out, w, nullptr, g_in, B, H, W, IC_CO);
+  else if (cout == 4) thin_to_fat_conv_kernel<4, true><<<grid, 256, 0, st>>>(g_out, w, nullptr, g_in, B, H, W, IC_CO);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
+                       int W, int cout, hipStream_t st) {
+  const int64_t M = (int64_t)B * H * W;
+  const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
+  if (cout == 1) fat_to_thin_conv_kernel<1><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
+  else if (cout == 4) fat_to_thin_conv_kernel<4><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_small_conv_wgrad_blocks(int B, int H, int W) {
+  return cdiv((int64_t)B * H * W, WGRAD_PIX);
+}
+int tdx_small_conv_partial_width(void) { return SMALLP_W; }
+
+int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
+                           int B, int H, int W, int cin, int cout_real, hipStream_t st) {
+  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
+  if (W < 4) return TDX_E_SHAPE;
+  if (cin == 1 && cout_real == 64)
+    thin_fat_wgrad_kernel<1, false><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, WGRAD_PIX, cout_real);
+  else if (cin == 4 && cout_real == 32)
+    thin_fat_wgrad_kernel<4, false><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, WGRAD_PIX, cout_real);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
+  const int nw = cout_real * cin * 9;
+  return reduce_partials2(partial, dw, db, nw, nblk, SMALLP_W, nw + cout_real, st);
+}
+
+int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
+                         int B, int H, int W, int cout, hipStream_t st) {
+  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
+  if (W < 4) return TDX_E_SHAPE;
+  if (cout == 1) thin_fat_wgrad_kernel<1, true><<<nblk, 256, 0, st>>>(g_out, in, partial, B, H, W, WGRAD_PIX, IC_CO);
+  else if (cout == 4) thin_fat_wgrad_kernel<4, true><<<nblk, 256, 0, st>>>(g_out, in, partial, B, H, W, WGRAD_PIX, IC_CO);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return reduce_partials2(partial, dw, db, cout * 576, nblk, SMALLP_W, cout * 576 + cout, st);
+}

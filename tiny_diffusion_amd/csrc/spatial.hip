@@ -2,8 +2,7 @@
 // on load so that normalised activations are never materialised:
 //   MaxPool2d(2, ceil_mode=True)                 diffusion.py:101, 120-124
 //   bilinear resize, align_corners=True          diffusion.py:102, 135-159
-//   initial_conv (Cin = 1) / final_conv (Cout = 1)   diffusion.py:28, 98, 116, 160
-// and their backward passes.
+// and their backward passes (the boundary convolutions initial_conv / final_conv live in edge_conv.hip).
 #include "internal.h"
 
 __device__ static inline float4 bnrelu4(float4 v, const float4& sc, const float4& sh) {
@@ -473,393 +472,4 @@ int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t 
   return 0;
 }
 
-// out[i] = sum_b partial[b*stride + i], i < count.  Fixed summation order (deterministic),
-// double accumulation; block = 32 columns x 8 interleaved row slices.  Columns >= split go to out2
-// (the bias gradient behind the weight gradient in one partial row).
-__global__ void __launch_bounds__(256)
-reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, float* __restrict__ out2,
-                       int split, int nblk, int stride, int count) {
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl;
-  double s = 0.0;
-  if (i < count) {
-#pragma unroll 4
-    for (int b = sl; b < nblk; b += 8) s += (double)partial[(size_t)b * stride + i];
-  }
-  red[sl][cl] = s;
-  __syncthreads();
-  if (sl == 0 && i < count) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
-    if (i < split) out[i] = (float)t;
-    else out2[i - split] = (float)t;
-  }
-}
-
-// First level of a long reduction, IN PLACE: block (c, g) sums the rows congruent to g modulo
-// gridDim.y over its 32 columns and stores the sum into row g.  No block reads what another one
-// writes (rows of another residue class, or other columns), and a block has read all of its rows
-// before it writes (barrier), so nblk rows become gridDim.y rows with no second buffer.  With
-// 3136 rows (B = 256 at 28x28) the one-level kernel above was 18 workgroups walking 392 dependent
-// loads each: 100+ us on the tail of the training step for a 576-float result.
-__global__ void __launch_bounds__(256)
-fold_partials_kernel(float* __restrict__ partial, int nblk, int stride, int count) {
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl, g = blockIdx.y, G = gridDim.y;
-  double s = 0.0;
-  if (i < count) {
-#pragma unroll 4
-    for (int b = g + sl * G; b < nblk; b += 8 * G) s += (double)partial[(size_t)b * stride + i];
-  }
-  red[sl][cl] = s;
-  __syncthreads();
-  if (sl == 0 && i < count) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
-    partial[(size_t)g * stride + i] = (float)t;
-  }
-}
-
-constexpr int FOLD_ROWS = 32;
-
-// out[0..split) and out2[0..count-split) from the columns of `partial` (which is consumed)
-static int reduce_partials2(float* partial, float* out, float* out2, int split, int nblk, int stride, int count,
-                            hipStream_t st) {
-  if (nblk > 4 * FOLD_ROWS) {
-    fold_partials_kernel<<<dim3(cdiv(count, 32), FOLD_ROWS), 256, 0, st>>>(partial, nblk, stride, count);
-    TDX_CHECK_LAUNCH();
-    nblk = FOLD_ROWS;
-  }
-  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, out2, split, nblk, stride, count);
-  TDX_CHECK_LAUNCH();
-  return 0;
-}
-
-int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
-                        hipStream_t st) {
-  reduce_partials_kernel<<<cdiv(count, 32), 256, 0, st>>>(partial, out, nullptr, count, nblk, stride, count);
-  TDX_CHECK_LAUNCH();
-  return 0;
-}
-
-// ------------------------------------- initial_conv (CIN -> COR, stored as 64 channels)
-// out[p][co] = b[co] + sum_ci sum_tap x[n][ci][p+tap] * W[co][ci][tap]; memory-bound (256 B
-// written per pixel).  x is the model input in the reference's NCHW layout
-// (1x28x28: diffusion.py:30; 4x32x32 latents: conditional_diffusion_laion.py:244); the output
-// is channels-last with a fixed stride of 64, channels >= COR written as zeros.
-#define IC_CO 64
-#define SMALLP_W 2368  // floats per block in the small-conv wgrad partial buffer (4*64*9 + 64)
-template <int CIN, int COR>
-__global__ void __launch_bounds__(256)
-initial_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
-  __shared__ float ws[CIN * 9][IC_CO];
-  __shared__ float bs[IC_CO];
-  // w is [co][ci][tap]
-  for (int i = threadIdx.x; i < CIN * 9 * IC_CO; i += 256) {
-    const int co = i / (CIN * 9), k = i % (CIN * 9);
-    ws[k][co] = co < COR ? w[i] : 0.f;
-  }
-  if (threadIdx.x < IC_CO) bs[threadIdx.x] = threadIdx.x < COR ? bias[threadIdx.x] : 0.f;
-  __syncthreads();
-  const int co = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int HW = H * W;
-  const int64_t M = (int64_t)B * HW;
-  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
-    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), oh = r / W, ow = r % W;
-    const float* xb = x + (int64_t)n * CIN * HW + r;
-    float4 acc = make_float4(bs[co], bs[co + 1], bs[co + 2], bs[co + 3]);
-#pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float xv = xb[ci * HW + (tap / 3 - 1) * W + (tap % 3 - 1)];
-          const int k = ci * 9 + tap;
-          acc.x = fmaf(xv, ws[k][co], acc.x);
-          acc.y = fmaf(xv, ws[k][co + 1], acc.y);
-          acc.z = fmaf(xv, ws[k][co + 2], acc.z);
-          acc.w = fmaf(xv, ws[k][co + 3], acc.w);
-        }
-      }
-    }
-    *reinterpret_cast<float4*>(out + p * IC_CO + co) = acc;
-  }
-}
-
-int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                         int W, int cin, int cout_real, hipStream_t st) {
-  const int64_t M = (int64_t)B * H * W;
-  const int grid = ew_grid(M, 16, 8192);
-  if (cin == 1 && cout_real == 64) initial_conv_fwd_kernel<1, 64><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W);
-  else if (cin == 4 && cout_real == 32) initial_conv_fwd_kernel<4, 32><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W);
-  else return TDX_E_SHAPE;
-  TDX_CHECK_LAUNCH();
-  return 0;
-}
-
-// dW[co][ci][tap] = sum_p g[p][co] * x[n][ci][p+tap];  db[co] = sum_p g[p][co]
-// partial[blk][SMALLP_W]: [(co*CIN+ci)*9+tap] then [COR*CIN*9 + co]
-// Pixels per block of the two boundary-convolution weight gradients: small, so that the grid has
-// thousands of blocks (the kernels are latency-bound) - but no smaller than needed for ~4096 blocks:
-// every block writes a partial row of SMALLP_W floats that a second pass sums, and at 64 pixels the
-// (4,64,64) LAION step wrote and re-read 190 MB of partials per kernel (1.5 + 0.8 + 0.9 ms of a 41 ms step).
-static int icw_pix(int64_t M) { return M >= 4096 * 256 ? 256 : M >= 4096 * 128 ? 128 : 64; }
-
-// first pixel of a thread and its (image, row, column); advanced by 4 pixels per iteration without
-// divisions (W >= 4)
-struct PixWalk {
-  int n, oh, ow;
-  __device__ PixWalk(int64_t p, int HW, int W) {
-    n = (int)(p / HW);
-    const int r = (int)(p - (int64_t)n * HW);
-    oh = r / W;
-    ow = r - oh * W;
-  }
-  __device__ void step4(int H, int W) {
-    ow += 4;
-    if (ow >= W) { ow -= W; if (++oh == H) { oh = 0; ++n; } }
-  }
-};
-template <int CIN, int COR>
-__global__ void __launch_bounds__(256)
-initial_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                          float* __restrict__ partial, int B, int H, int W, int pix) {
-  constexpr int NA = CIN * 9 + 1;
-  __shared__ float red[4][NA][IC_CO];
-  const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int HW = H * W;
-  const int64_t M = (int64_t)B * HW;
-  const int64_t p0 = (int64_t)blockIdx.x * pix, p1 = min(p0 + pix, M);
-  float acc[NA];
-#pragma unroll
-  for (int k = 0; k < NA; ++k) acc[k] = 0.f;
-  PixWalk pw(min(p0 + pg, M - 1), HW, W);
-  for (int64_t p = p0 + pg; p < p1; p += 4, pw.step4(H, W)) {
-    const float gv = g[p * IC_CO + co];
-    const int n = pw.n, oh = pw.oh, ow = pw.ow, r = oh * W + ow;
-    const float* xb = x + (int64_t)n * CIN * HW + r;
-#pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-          acc[ci * 9 + tap] = fmaf(gv, xb[ci * HW + (tap / 3 - 1) * W + (tap % 3 - 1)], acc[ci * 9 + tap]);
-      }
-    }
-    acc[NA - 1] += gv;
-  }
-#pragma unroll
-  for (int k = 0; k < NA; ++k) red[pg][k][co] = acc[k];
-  __syncthreads();
-  if (pg == 0 && co < COR) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const float v = red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co];
-      partial[(size_t)blockIdx.x * SMALLP_W + (k < NA - 1 ? co * (CIN * 9) + k : COR * CIN * 9 + co)] = v;
-    }
-  }
-}
-
-int tdx_small_conv_wgrad_blocks(int B, int H, int W) {
-  const int64_t M = (int64_t)B * H * W;
-  return cdiv(M, icw_pix(M));
-}
-int tdx_small_conv_partial_width(void) { return SMALLP_W; }
-
-int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
-                           int B, int H, int W, int cin, int cout_real, hipStream_t st) {
-  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
-  const int pix = icw_pix((int64_t)B * H * W);
-  if (W < 4) return TDX_E_SHAPE;
-  if (cin == 1 && cout_real == 64) initial_conv_wgrad_kernel<1, 64><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, pix);
-  else if (cin == 4 && cout_real == 32) initial_conv_wgrad_kernel<4, 32><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, pix);
-  else return TDX_E_SHAPE;
-  TDX_CHECK_LAUNCH();
-  // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
-  const int nw = cout_real * cin * 9;
-  return reduce_partials2(partial, dw, db, nw, nblk, SMALLP_W, nw + cout_real, st);
-}
-
-// ------------------------------------------------------ final_conv (64 -> CO)
-// out[n][co][p] = b[co] + sum_tap sum_ci in[p+tap][ci] * W[co][ci][tap]; 16 lanes per pixel,
-// float4 of channels per lane, shuffle-reduced.  Output in the reference's NCHW layout.
-template <int CO>
-__global__ void __launch_bounds__(256)
-final_conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                      const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
-  __shared__ float ws[CO][9][IC_CO];
-  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {  // w is [co][ci][tap]
-    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
-    ws[co][r % 9][r / 9] = w[i];
-  }
-  __syncthreads();
-  const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int HW = H * W;
-  const int64_t M = (int64_t)B * HW;
-  const int64_t Mpad = (M + 15) / 16 * 16;
-  float bv[CO];
-#pragma unroll
-  for (int co = 0; co < CO; ++co) bv[co] = bias[co];
-  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
-    float s[CO];
-#pragma unroll
-    for (int co = 0; co < CO; ++co) s[co] = 0.f;
-    int n = 0, r = 0;
-    if (p < M) {
-      n = (int)(p / HW);
-      r = (int)(p - (int64_t)n * HW);
-      const int oh = r / W, ow = r % W;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float4 v = *reinterpret_cast<const float4*>(
-              in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
-#pragma unroll
-          for (int co = 0; co < CO; ++co) {
-            s[co] = fmaf(v.x, ws[co][tap][ci], s[co]);
-            s[co] = fmaf(v.y, ws[co][tap][ci + 1], s[co]);
-            s[co] = fmaf(v.z, ws[co][tap][ci + 2], s[co]);
-            s[co] = fmaf(v.w, ws[co][tap][ci + 3], s[co]);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-      s[co] += __shfl_xor(s[co], 8, 64);
-      s[co] += __shfl_xor(s[co], 4, 64);
-      s[co] += __shfl_xor(s[co], 2, 64);
-      s[co] += __shfl_xor(s[co], 1, 64);
-    }
-    if ((threadIdx.x & 15) == 0 && p < M) {
-#pragma unroll
-      for (int co = 0; co < CO; ++co) out[((int64_t)n * CO + co) * HW + r] = s[co] + bv[co];
-    }
-  }
-}
-
-int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
-                       int W, int cout, hipStream_t st) {
-  const int64_t M = (int64_t)B * H * W;
-  const int grid = ew_grid(M, 16, 8192);
-  if (cout == 1) final_conv_fwd_kernel<1><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
-  else if (cout == 4) final_conv_fwd_kernel<4><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
-  else return TDX_E_SHAPE;
-  TDX_CHECK_LAUNCH();
-  return 0;
-}
-
-// g_in[p][ci] = sum_co sum_tap g_out[n][co][p - tapoffset] * W[co][ci][tap]
-template <int CO>
-__global__ void __launch_bounds__(256)
-final_conv_dgrad_kernel(const float* __restrict__ g_out, const float* __restrict__ w,
-                        float* __restrict__ g_in, int B, int H, int W) {
-  __shared__ float ws[CO][9][IC_CO];
-  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {
-    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
-    ws[co][r % 9][r / 9] = w[i];
-  }
-  __syncthreads();
-  const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
-  const int HW = H * W;
-  const int64_t M = (int64_t)B * HW;
-  for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < M; p += (int64_t)gridDim.x * 16) {
-    const int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW), ih = r / W, iw = r % W;
-    const float* gb = g_out + (int64_t)n * CO * HW + r;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        // output pixel (oh, ow) saw this input through tap (kh, kw) iff oh = ih - kh + 1
-        const int oh = ih - (tap / 3 - 1), ow = iw - (tap % 3 - 1);
-        if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
-          const float gv = gb[co * HW - (tap / 3 - 1) * W - (tap % 3 - 1)];
-          acc.x = fmaf(gv, ws[co][tap][ci], acc.x);
-          acc.y = fmaf(gv, ws[co][tap][ci + 1], acc.y);
-          acc.z = fmaf(gv, ws[co][tap][ci + 2], acc.z);
-          acc.w = fmaf(gv, ws[co][tap][ci + 3], acc.w);
-        }
-      }
-    }
-    *reinterpret_cast<float4*>(g_in + p * IC_CO + ci) = acc;
-  }
-}
-
-int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
-                         int cout, hipStream_t st) {
-  const int64_t M = (int64_t)B * H * W;
-  const int grid = ew_grid(M, 16, 8192);
-  if (cout == 1) final_conv_dgrad_kernel<1><<<grid, 256, 0, st>>>(g_out, w, g_in, B, H, W);
-  else if (cout == 4) final_conv_dgrad_kernel<4><<<grid, 256, 0, st>>>(g_out, w, g_in, B, H, W);
-  else return TDX_E_SHAPE;
-  TDX_CHECK_LAUNCH();
-  return 0;
-}
-
-// dW[co][ci][tap] = sum_p g_out[n][co][p] * in[p+tap][ci];  db[co] = sum_p g_out[n][co][p]
-// partial[blk][SMALLP_W]: [(co*64+ci)*9+tap], then [CO*576 + co] = db partials
-template <int CO>
-__global__ void __launch_bounds__(256)
-final_conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ g_out,
-                        float* __restrict__ partial, int B, int H, int W, int pix) {
-  constexpr int NA = CO * 10;
-  __shared__ float red[4][NA][IC_CO];
-  const int ci = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int HW = H * W;
-  const int64_t M = (int64_t)B * HW;
-  const int64_t p0 = (int64_t)blockIdx.x * pix, p1 = min(p0 + pix, M);
-  float acc[NA];
-#pragma unroll
-  for (int k = 0; k < NA; ++k) acc[k] = 0.f;
-  PixWalk pw(min(p0 + pg, M - 1), HW, W);
-  for (int64_t p = p0 + pg; p < p1; p += 4, pw.step4(H, W)) {
-    const int n = pw.n, oh = pw.oh, ow = pw.ow, r = oh * W + ow;
-    float gv[CO];
-#pragma unroll
-    for (int co = 0; co < CO; ++co) gv[co] = g_out[((int64_t)n * CO + co) * HW + r];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-        const float v = in[(p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci];
-#pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co * 10 + tap] = fmaf(gv[co], v, acc[co * 10 + tap]);
-      }
-    }
-#pragma unroll
-    for (int co = 0; co < CO; ++co) acc[co * 10 + 9] += gv[co];
-  }
-#pragma unroll
-  for (int k = 0; k < NA; ++k) red[pg][k][ci] = acc[k];
-  __syncthreads();
-  if (pg == 0) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int co = k / 10, tap = k % 10;
-      const float v = red[0][k][ci] + red[1][k][ci] + red[2][k][ci] + red[3][k][ci];
-      if (tap < 9) partial[(size_t)blockIdx.x * SMALLP_W + (co * IC_CO + ci) * 9 + tap] = v;
-      else if (ci == 0) partial[(size_t)blockIdx.x * SMALLP_W + CO * 576 + co] = v;
-    }
-  }
-}
-
-int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
-                         int B, int H, int W, int cout, hipStream_t st) {
-  const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
-  const int pix = icw_pix((int64_t)B * H * W);
-  if (W < 4) return TDX_E_SHAPE;
-  if (cout == 1) final_conv_wgrad_kernel<1><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W, pix);
-  else if (cout == 4) final_conv_wgrad_kernel<4><<<nblk, 256, 0, st>>>(in, g_out, partial, B, H, W, pix);
-  else return TDX_E_SHAPE;
-  TDX_CHECK_LAUNCH();
-  return reduce_partials2(partial, dw, db, cout * 576, nblk, SMALLP_W, cout * 576 + cout, st);
-}
+// initial_conv / final_conv and their backward passes: edge_conv.hip
