@@ -8,7 +8,7 @@
 // the same arithmetic as the CUDA-core loops they replace, up to summation order) with the thin
 // operand gathered straight from the (L2-resident) NCHW tensor:
 //   thin_to_fat_conv   out[p][c] = b[c] + sum_k T[p][k] W[k][c]      initial_conv forward; final_conv dgrad (taps mirrored)
-//   fat_to_thin_conv   out[n][o][p] = b[o] + sum_{tap,c} F[p+tap][c] W[o][c][tap]      final_conv forward (VALU, weights in registers)
+//   fat_to_thin_conv   out[n][o][p] = b[o] + sum_{tap,c} F[p+tap][c] W[o][c][tap]      final_conv forward (VALU, weights in LDS)
 //   thin_fat_wgrad     dW[k][c] = sum_p T[p][k] F[p][c]              both weight gradients (+ bias gradients)
 // T[p][k = (ch, tap)] = thin[n][ch][pixel p shifted by the tap] (0 outside the image).
 // Before (B = 256, LAION 4x32x32, us): 107 / 142 / 54 / 408 / 382 of a 10.1 ms step, mostly exposed at its head and tail.
@@ -110,27 +110,28 @@ thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict_
 }
 
 // ------------------------------------------------------------------ fat -> thin
-// out[n][o][p] = b[o] + sum_tap sum_c in[p+tap][c] * W[o][c][tap]; 16 lanes per pixel, each with four
-// channels of the pixel and ITS weights (CO x 9 x 4) in registers; shuffle-reduced over the 16 lanes.
+// out[n][o][p] = b[o] + sum_tap sum_c in[p+tap][c] * W[o][c][tap]; 16 lanes per pixel, a float4 of
+// channels per lane, weights in LDS, shuffle-reduced over the 16 lanes.  (Weights in registers - CO*9
+// float4 per lane - was tried: 210 VGPRs, two waves per SIMD, 152 us instead of 54 at CO = 4.  What is
+// left on the table is the LDS weight traffic, one b128 read per four FMAs; the GEMM form
+// Z[q][(o,tap)] = in[q][:] . W[o][:][tap] followed by a 9-neighbour gather would read `in` once.)
 template <int CO>
 __global__ void __launch_bounds__(256)
 fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
                         const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float ws[CO][9][IC_CO];
+  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {  // w is [co][ci][tap]
+    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
+    ws[co][r % 9][r / 9] = w[i];
+  }
+  __syncthreads();
   const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
   const int HW = H * W;
   const int64_t M = (int64_t)B * HW;
   const int64_t Mpad = (M + 15) / 16 * 16;
-  float4 wr[CO][9];
   float bv[CO];
 #pragma unroll
-  for (int co = 0; co < CO; ++co) {
-    bv[co] = bias[co];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* q = w + (co * IC_CO + ci) * 9 + tap;  // w is [co][c][tap]
-      wr[co][tap] = make_float4(q[0], q[9], q[18], q[27]);
-    }
-  }
+  for (int co = 0; co < CO; ++co) bv[co] = bias[co];
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
     float s[CO];
 #pragma unroll
@@ -148,10 +149,11 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
               in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
 #pragma unroll
           for (int co = 0; co < CO; ++co) {
-            s[co] = fmaf(v.x, wr[co][tap].x, s[co]);
-            s[co] = fmaf(v.y, wr[co][tap].y, s[co]);
-            s[co] = fmaf(v.z, wr[co][tap].z, s[co]);
-            s[co] = fmaf(v.w, wr[co][tap].w, s[co]);
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[co][tap][ci]);
+            s[co] = fmaf(v.x, wv.x, s[co]);
+            s[co] = fmaf(v.y, wv.y, s[co]);
+            s[co] = fmaf(v.z, wv.z, s[co]);
+            s[co] = fmaf(v.w, wv.w, s[co]);
           }
         }
       }

@@ -27,8 +27,12 @@ int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st, int td = 0, bool proj_done = false);
-// one projection's share of the above (time_embed.hip); then tdx_time_embed_bwd(..., proj_done = true)
+                       hipStream_t st, int td = 0, int parts = 7);
+// `parts` of the time path's backward, in dependency order: the three projections (dW, db, their sum into
+// g(emb)); the middle (class embedding, second linear layer, and for kind 1 the first one too); kind 0's
+// first layer (time_l1_bwd_kernel).  A caller may issue them at different times (unet.hip).
+enum { TDX_TIME_PROJ = 1, TDX_TIME_MID = 2, TDX_TIME_L1 = 4 };
+// one projection's share of TDX_TIME_PROJ (time_embed.hip)
 int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
                       const float* g_tk, float* scratch, int B, hipStream_t st, int td = 0);
 int tdx_conv3x3_fwd_splitk_fused(const float* in, const float* wpk, const float* bias, float* out, int B, int H,
@@ -54,7 +58,7 @@ int tdx_conv3x3_wgrad_reduce_pad(const float* dw_slabs, float* dw_oihw, int spli
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64 = nullptr, int td = 0, bool proj_done = false);
+                          const int64_t* t_i64 = nullptr, int td = 0, int parts = 7);
 // synchronised BatchNorm pieces (bn.hip); tdx_allreduce_fn: include/tdx.h
 int tdx_bn_moments(const float* stats_partial, int tiles, int tile_rows, int64_t count, int C, double* mom,
                    hipStream_t st);

@@ -423,19 +423,20 @@ __global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int6
 // no gradient flows to them
 static int time_embed_bwd_laion(const float* const* P, float* const* G, const float* sin, const float* pre,
                                 const float* emb, const float* g_t1, const float* g_t2, const float* g_t3,
-                                float* scratch, int B, int td, hipStream_t st, bool proj_done) {
+                                float* scratch, int B, int td, hipStream_t st, int parts) {
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * td;
   float* g_h = scratch + (size_t)2 * B * td;
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int ok[3] = {64, 128, 256};
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
-  for (int k = 0; k < 3 && !proj_done; ++k) {
+  for (int k = 0; k < 3 && (parts & TDX_TIME_PROJ); ++k) {
     lin_wgrad_kernel<<<cdiv(ok[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B, ok[k], td, ok[k]);
     TDX_CHECK_LAUNCH();
     lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(gk[k], P[pw[k]], g_emb, B, ok[k], td, k > 0, ok[k]);
     TDX_CHECK_LAUNCH();
   }
+  if (!(parts & TDX_TIME_MID)) return 0;   // this kind has no separate first-layer part: MID is the rest
   silu_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(pre, h, B * td);
   TDX_CHECK_LAUNCH();
   lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, td, td, td);
@@ -454,13 +455,13 @@ static int time_embed_bwd_laion(const float* const* P, float* const* G, const fl
 int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const* P, float* const* G,
                           const float* pre, const float* emb, const float* const* gk, const int* ldg,
                           const int* widths, float* scratch, int B, int ncls, hipStream_t st,
-                          const int64_t* t_i64, int td, bool proj_done) {
+                          const int64_t* t_i64, int td, int parts) {
   if (td <= 0) td = TD;
   float* g_emb = scratch;
   float* h = scratch + (size_t)B * td;
   float* g_h = scratch + (size_t)2 * B * td;
   const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
-  for (int k = 0; k < 3 && !proj_done; ++k) {
+  for (int k = 0; k < 3 && (parts & TDX_TIME_PROJ); ++k) {
     lin_wgrad_kernel<<<cdiv(widths[k] * td, 256), 256, 0, st>>>(gk[k], emb, G[pw[k]], G[pw[k] + 1], B,
                                                                 widths[k], td, ldg[k]);
     TDX_CHECK_LAUNCH();
@@ -468,16 +469,19 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
                                                         ldg[k]);
     TDX_CHECK_LAUNCH();
   }
-  if (ncls > 0 && y) {
-    class_emb_bwd_kernel<<<cdiv(ncls * td, 256), 256, 0, st>>>(g_emb, y, G[TDX_P_CLASS_EMB], B, ncls, td);
+  if (parts & TDX_TIME_MID) {
+    if (ncls > 0 && y) {
+      class_emb_bwd_kernel<<<cdiv(ncls * td, 256), 256, 0, st>>>(g_emb, y, G[TDX_P_CLASS_EMB], B, ncls, td);
+      TDX_CHECK_LAUNCH();
+    }
+    silu_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(pre, h, B * td);
+    TDX_CHECK_LAUNCH();
+    lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, td, td, td);
+    TDX_CHECK_LAUNCH();
+    lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, td, td, 0, td);
     TDX_CHECK_LAUNCH();
   }
-  silu_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(pre, h, B * td);
-  TDX_CHECK_LAUNCH();
-  lin_wgrad_kernel<<<cdiv(td * td, 256), 256, 0, st>>>(g_emb, h, G[TDX_P_TE2_W], G[TDX_P_TE2_B], B, td, td, td);
-  TDX_CHECK_LAUNCH();
-  lin_dgrad_kernel<<<cdiv(B * td, 256), 256, 0, st>>>(g_emb, P[TDX_P_TE2_W], g_h, B, td, td, 0, td);
-  TDX_CHECK_LAUNCH();
+  if (!(parts & TDX_TIME_L1)) return 0;
   if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer && td == TD)
     time_l1_bwd_i64_dbg_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B,
                                                         g_tdx_diag_buffer);
@@ -492,21 +496,20 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
 int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float* const* P, float* const* G,
                        const float* sin, const float* pre, const float* emb, const float* g_t1,
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
-                       hipStream_t st, int td, bool proj_done) {
+                       hipStream_t st, int td, int parts) {
   if (td <= 0) td = kind == 1 ? TDL : TD;
   if (td % 256 || td > 1024) return TDX_E_SHAPE;
   if (kind == 1)
-    return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st, proj_done);
+    return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st, parts);
   const float* gk[3] = {g_t1, g_t2, g_t3};
   const int widths[3] = {128, 256, 512};
-  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t, td,
-                               proj_done);
+  return tdx_time_embed_bwd_ex(sin, y, P, G, pre, emb, gk, widths, widths, scratch, B, ncls, st, t, td, parts);
 }
 
 // Backward of ONE time projection (k = 0, 1, 2 <-> time_proj1/2/3), for a caller that has the three
 // pixel sums at different times: dW_k, db_k and the projection's contribution to g_emb = scratch[0 : B*td]
 // (k = 0 overwrites, k > 0 accumulates: call in the order 0, 1, 2, the summation order of the whole-path
-// function above, then that function with proj_done).
+// function above, then that function without TDX_TIME_PROJ in `parts`).
 int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
                       const float* g_tk, float* scratch, int B, hipStream_t st, int td) {
   if (td <= 0) td = kind == 1 ? TDL : TD;

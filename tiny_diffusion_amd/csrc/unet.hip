@@ -554,8 +554,18 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     }
   }
 
+  // The time / class MLP feeds only the skip branches (t_k is added where e_k is resized into the decoder's
+  // concat buffer) and the backward: in the training modes all of that lives on the third stream, so the MLP
+  // runs there too, beside initial_conv and the first encoder level (LAION, 768 wide: 90 us off the head
+  // of the step).  Sampling is one stream.
+  hipStream_t tst = st;
+  if (!infer && u->side2 != st) {
+    TDX_HIP(hipEventRecord(u->ev_fork, st));   // t / labels / cond are in place
+    TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
+    tst = u->side2;
+  }
   RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],
-                        ws + L.tp[1], ws + L.tp[2], B, st, S.time_dim));
+                        ws + L.tp[1], ws + L.tp[2], B, tst, S.time_dim));
   RC(tdx_initial_conv_fwd(x, P[TDX_P_INIT_W], P[TDX_P_INIT_B], ws + L.x0, B, S.hw0, S.hw0, S.in_ch,
                           S.x0_real, st));
 
@@ -817,6 +827,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   };
   auto ssc = [&](int i) { return ws + L.ss[i]; };
   auto ssh = [&](int i) { return ws + L.ss[i] + S.units[i].cout; };
+  // the time / class path's backward on the third stream, in `parts` (internal.h)
+  auto time_path_parts = [&](int parts) -> int {
+    return tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
+                              u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
+                              P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
+                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2, S.time_dim, parts);
+  };
   // first unit of a decoder level (stages 2, 4, 6 = units 11, 9, 7): after its dgrad the
   // gradient of the concatenated input is split into the up-sampled branch and the skip branch
   auto dec_level_bwd = [&](int k) -> int {  // k = 2 (dec1), 1 (dec2), 0 (dec3)
@@ -840,9 +857,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     // arrive in the order time_proj1, 2, 3 = the summation order of tdx_time_embed_bwd): six of the
     // time path's small kernels leave the tail of the step.  The REST of that path stays after the last
     // stage (see time_path_bwd).
-    if (g_tdx_time_proj_early)
+    if (g_tdx_time_proj_early) {
       RC(tdx_time_proj_bwd(u->kind, skip_k, P, G, ws + L.emb, ws + L.gtp[skip_k], ws + L.timescr, B, u->side2,
                            S.time_dim));
+      // after the third projection g(emb) is complete: the middle of the time path follows at once (for kind 1
+      // that is all of it); only kind 0's first-layer kernel waits for the last stage (see time_path_bwd)
+      if (skip_k == 2 && g_tdx_time_stage != 6) RC(time_path_parts(TDX_TIME_MID));
+    }
     find(gcat)->s2 = k;
     float* gup;
     RC(acquire(gcat, nullptr, &gup));
@@ -862,11 +883,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   auto time_path_bwd = [&](hipStream_t st) -> int {
     TDX_HIP(hipEventRecord(u->ev_fork, st));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
-    return tdx_time_embed_bwd(u->kind, reinterpret_cast<const int64_t*>(ws + L.t),
-                              u->num_classes > 0 ? reinterpret_cast<const int64_t*>(ws + L.y) : nullptr,
-                              P, G, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.gtp[0], ws + L.gtp[1],
-                              ws + L.gtp[2], ws + L.timescr, B, u->num_classes, u->side2, S.time_dim,
-                              g_tdx_time_proj_early != 0);
+    // what dec_level_bwd has not issued already
+    const int parts = !g_tdx_time_proj_early ? 7 : g_tdx_time_stage == 6 ? (TDX_TIME_MID | TDX_TIME_L1) : TDX_TIME_L1;
+    if (parts == TDX_TIME_L1 && u->kind == 1) return 0;   // kind 1 has no separate first-layer part
+    return time_path_parts(parts);
   };
   // first unit of an encoder level below the top, or the bottleneck (units 6, 4, 2): its input is a
   // pooled tensor; route the gradient through the max-pool and add the skip-path gradient
@@ -896,9 +916,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
           float *gd1a, *g12;
           RC(acquire(nullptr, nullptr, &gd1a));
           RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], gd1a, B, S.out_hw, S.out_hw, S.in_ch, st));
-          RC(acquire(gd1a, nullptr, &g12));
-          RC(tdx_bilinear_ac_bwd(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
-          g_next = g12;
+          if (S.dec_hw[2] == S.out_hw) {  // the output resize is the identity (LAION network): so is its adjoint
+            g_next = gd1a;
+          } else {
+            RC(acquire(gd1a, nullptr, &g12));
+            RC(tdx_bilinear_ac_bwd(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
+            g_next = g12;
+          }
         }
         break;
       case 1: RC(plain_unit_bwd(12, ws + L.Y[11])); break;

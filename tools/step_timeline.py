@@ -21,7 +21,7 @@ queues = {}
 
 
 def short(n):
-    return n.replace("void ", "").split("(")[0][:52]
+    return n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:52]
 
 
 def isconv(n):
