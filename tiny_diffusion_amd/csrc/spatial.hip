@@ -340,52 +340,40 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ g_out, float* __re
 // re-deriving 16 axis taps and testing 64 weight products per element.  Same contributors, same
 // weights, same summation order (rows ascending, columns ascending) => bit-identical results.
 #define BIL_ROW_MAXW 64
+// one axis' contributor window of input index i, compacted to its non-zero span: weights w[0..n), first output lo
+__device__ static inline void axis_window(int i, float scale, int n_in, int n_out, float* w_out, int& lo_out,
+                                          int& n_out_w) {
+  int lo;
+  float w[BIL_MAXC];
+  axis_adjoint(i, scale, n_in, n_out, lo, w);
+  int first = BIL_MAXC, last = -1;
+#pragma unroll
+  for (int k = 0; k < BIL_MAXC; ++k)
+    if (w[k] != 0.f) { first = min(first, k); last = k; }
+#pragma unroll
+  for (int k = 0; k < BIL_MAXC; ++k) w_out[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < BIL_MAXC; ++k)
+    if (k >= first && k <= last) w_out[k - first] = w[k];
+  lo_out = lo + (last >= 0 ? first : 0);
+  n_out_w = last >= 0 ? last - first + 1 : 0;
+}
+
 __global__ void __launch_bounds__(256)
 bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_in, int rows,
                          int Hi, int Wi, int Ho, int Wo, int C, int gcs, int gcoff, float sch,
                          float scw) {
-  __shared__ float s_ww[BIL_ROW_MAXW][BIL_MAXC];
-  __shared__ float s_wh[BIL_MAXC];
-  __shared__ int s_wlo[BIL_ROW_MAXW], s_wn[BIL_ROW_MAXW], s_h[2];
+  __shared__ float s_ww[BIL_ROW_MAXW][BIL_MAXC], s_wh[BIL_ROW_MAXW][BIL_MAXC];
+  __shared__ int s_wlo[BIL_ROW_MAXW], s_wn[BIL_ROW_MAXW], s_hlo[BIL_ROW_MAXW], s_hn[BIL_ROW_MAXW];
   const int tid = threadIdx.x, c4n = C / 4, per_row = Wi * c4n;
-  // the W-axis windows do not depend on the row
-  if (tid < Wi) {
-    int lo;
-    float w[BIL_MAXC];
-    axis_adjoint(tid, scw, Wi, Wo, lo, w);
-    int first = BIL_MAXC, last = -1;
-#pragma unroll
-    for (int k = 0; k < BIL_MAXC; ++k)
-      if (w[k] != 0.f) { first = min(first, k); last = k; }
-#pragma unroll
-    for (int k = 0; k < BIL_MAXC; ++k) s_ww[tid][k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < BIL_MAXC; ++k)
-      if (k >= first && k <= last) s_ww[tid][k - first] = w[k];
-    s_wlo[tid] = lo + (last >= 0 ? first : 0);
-    s_wn[tid] = last >= 0 ? last - first + 1 : 0;
-  }
+  // both axes' windows depend only on the index along the axis: all of them once per workgroup (Hi, Wi <= 64),
+  // then rows are walked with no barrier and no tap arithmetic in the loop
+  if (tid < Wi) axis_window(tid, scw, Wi, Wo, s_ww[tid], s_wlo[tid], s_wn[tid]);
+  else if (tid >= 64 && tid - 64 < Hi) axis_window(tid - 64, sch, Hi, Ho, s_wh[tid - 64], s_hlo[tid - 64], s_hn[tid - 64]);
+  __syncthreads();
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int b = r / Hi, ih = r - b * Hi;
-    __syncthreads();  // previous row's readers are done with s_wh / s_h (and s_ww is written)
-    if (tid == 64) {
-      int lo;
-      float w[BIL_MAXC];
-      axis_adjoint(ih, sch, Hi, Ho, lo, w);
-      int first = BIL_MAXC, last = -1;
-#pragma unroll
-      for (int k = 0; k < BIL_MAXC; ++k)
-        if (w[k] != 0.f) { first = min(first, k); last = k; }
-#pragma unroll
-      for (int k = 0; k < BIL_MAXC; ++k) s_wh[k] = 0.f;
-#pragma unroll
-      for (int k = 0; k < BIL_MAXC; ++k)
-        if (k >= first && k <= last) s_wh[k - first] = w[k];
-      s_h[0] = lo + (last >= 0 ? first : 0);
-      s_h[1] = last >= 0 ? last - first + 1 : 0;
-    }
-    __syncthreads();
-    const int hlo = s_h[0], hn = s_h[1];
+    const int hlo = s_hlo[ih], hn = s_hn[ih];
     const float* grow = g_out + ((int64_t)b * Ho + hlo) * Wo * gcs + gcoff;
     float* orow = g_in + (int64_t)r * per_row * 4;
     for (int j = tid; j < per_row; j += 256) {
@@ -393,7 +381,7 @@ bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_
       const int wlo = s_wlo[iw], wn = s_wn[iw];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int a = 0; a < hn; ++a) {
-        const float wa = s_wh[a];
+        const float wa = s_wh[ih][a];
         if (wa == 0.f) continue;
         const float* gp = grow + ((int64_t)a * Wo + wlo) * gcs + c;
         for (int d = 0; d < wn; ++d) {
@@ -430,7 +418,7 @@ extern "C" int tdx_bilinear_ac_bwd(const float* g_out, float* g_in, int B, int H
   if (C % 4 || g_cstride % 4 || g_coff % 4 || g_coff + C > g_cstride) return TDX_E_SHAPE;
   if (!adjoint_window_ok(Hi, Ho) || !adjoint_window_ok(Wi, Wo)) return TDX_E_SHAPE;
   const int64_t n = (int64_t)B * Hi * Wi * (C / 4);
-  if (Wi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30)) {
+  if (Wi <= BIL_ROW_MAXW && Hi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30)) {
     const int rows = B * Hi;
     bilinear_bwd_rows_kernel<<<rows < 16384 ? rows : 16384, 256, 0, to_stream(stream)>>>(
         g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
