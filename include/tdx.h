@@ -205,8 +205,10 @@ int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, 
  * Tensors stay fp32 in memory; the MFMA operands are rounded to bf16 (nearest even) while a tile is
  * staged, weights are packed to bf16 by tdx_pack_conv3x3_bf16 ([cout][9][cin] / [cin][9][cout], 2 bytes
  * per element).  Arguments as tdx_conv3x3_fwd / _wgrad; cin % 64 == 0, cout % 64 == 0; statistics
- * tiles are always tdx_conv3x3_bf16_stat_tile_rows() = 128 pixels; slabs / splits / reduce are those
- * of the fp32 weight gradient.  Tolerance: tests/test_gpu_bf16.py. */
+ * tiles are always tdx_conv3x3_bf16_stat_tile_rows() = 128 pixels; the weight gradient writes the fp32
+ * path's slab layout (same reduce) in tdx_conv3x3_wgrad_splits_bf16(...) slabs - its own split plan: the
+ * bf16 kernel is bound by L2 bandwidth, not MFMA rate, and wants bigger tiles.  Tolerance: tests/test_gpu_bf16.py. */
+int tdx_conv3x3_wgrad_splits_bf16(int B, int H, int W, int cin, int cout);
 int tdx_pack_conv3x3_bf16(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin,
                           tdx_stream_t stream);
 int tdx_conv3x3_bf16_stat_tile_rows(void);

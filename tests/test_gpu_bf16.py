@@ -107,7 +107,7 @@ def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
     check(lib.tdx_conv3x3_fwd_bf16(gd.data_ptr(), wg16.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
                                    None, None, None, None, None, st()))
     assert rel_err(nchw(gin), ref_dx) < 2e-5
-    splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)
     slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
     dw = torch.empty((cout, cin, 3, 3), device="cuda")
     check(lib.tdx_conv3x3_wgrad_bf16(xin.data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 0, None, None,
@@ -140,7 +140,7 @@ def test_bf16_conv_bn_relu_on_load_and_fused_epilogue(tdx):
     check(lib.tdx_conv3x3_fwd_bf16(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin, cout,
                                    1 | 2, iscd.data_ptr(), ishd.data_ptr(), oscd.data_ptr(), oshd.data_ptr(), None, st()))
     assert rel_err(nchw(out), ref.detach()) < 3e-5
-    splits = lib.tdx_conv3x3_wgrad_splits(B, H, H, cin, cout)
+    splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)
     slabs = torch.empty((splits, cout, 9, cin), device="cuda")
     dw = torch.empty((cout, cin, 3, 3), device="cuda")
     gd = nhwc(dy).cuda()

@@ -1375,14 +1375,16 @@ struct WgradCfg {
   int bm, bn, splits, chunk;
 };
 
-static WgradCfg pick_wgrad(int64_t M, int cin, int cout) {
+static WgradCfg pick_wgrad(int64_t M, int cin, int cout, bool bf16 = false) {
   WgradCfg c;
   c.bm = (cout % 128 == 0) ? 128 : 64;
   c.bn = (cin % 128 == 0) ? 128 : 64;
   // Deep layers have many weight tiles but few pixels: 128x128 tiles would need ~15 pixel splits
   // to fill the chip, i.e. 15 partial copies of a 9.4 MB gradient written and re-read by the
   // reduce (140 MB per layer).  64x64 tiles give 4x the workgroups from the weights alone.
-  if (g_wgrad_small && (int64_t)cout * cin >= (1 << 17) && M <= 16384) { c.bm = 64; c.bn = 64; }
+  // Not in bf16 mode: there a 64x64 tile (16 FLOP per operand byte from L2) is L2-bound at ~175 TFLOP/s -
+  // the four deep layers of the MNIST UNet ran at exactly that - and the bigger tile wins despite the slabs.
+  if (!bf16 && g_wgrad_small && (int64_t)cout * cin >= (1 << 17) && M <= 16384) { c.bm = 64; c.bn = 64; }
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
   const int target = (c.bm == 128 && c.bn == 128 && g_wgrad_target_big > 0) ? g_wgrad_target_big : g_wgrad_target;
   int64_t s = (target + tiles - 1) / tiles;
@@ -1410,13 +1412,16 @@ extern "C" int tdx_conv3x3_tile_shape(int B, int H, int W, int cin, int cout, in
 }
 
 // the split plan is shared with the bf16 kernels (same slab layout, same reduce)
-void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk) {
-  const WgradCfg c = pick_wgrad(M, cin, cout);
+void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk, bool bf16) {
+  const WgradCfg c = pick_wgrad(M, cin, cout, bf16);
   *bm = c.bm; *bn = c.bn; *splits = c.splits; *chunk = c.chunk;
 }
 
 extern "C" int tdx_conv3x3_wgrad_splits(int B, int H, int W, int cin, int cout) {
   return pick_wgrad((int64_t)B * H * W, cin, cout).splits;
+}
+extern "C" int tdx_conv3x3_wgrad_splits_bf16(int B, int H, int W, int cin, int cout) {
+  return pick_wgrad((int64_t)B * H * W, cin, cout, true).splits;
 }
 
 template <int BM, int BN>

@@ -519,7 +519,7 @@ extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* d
   if (!tdx_conv3x3_shape_ok(B, H, W, cin, cout)) return TDX_E_SHAPE;
   const int64_t M64 = (int64_t)B * H * W;
   int bm, bn, splits, chunk;
-  tdx_wgrad_plan(M64, cin, cout, &bm, &bn, &splits, &chunk);  // same splits / slab layout as the fp32 path
+  tdx_wgrad_plan(M64, cin, cout, &bm, &bn, &splits, &chunk, true);  // same slab layout and reduce as the fp32 path, own tiles / splits
   WgradArgs a;
   a.in = in; a.dy = dy; a.slabs = dw_slabs; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;

@@ -194,4 +194,4 @@ struct WgradArgs {
   int adv_q, adv_s;  // 32 pixels = adv_q rows + adv_s columns of a W-wide image
 };
 
-void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk);
+void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk, bool bf16 = false);

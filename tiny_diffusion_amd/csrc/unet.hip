@@ -123,8 +123,9 @@ Layout make_layout(const NetSpec& S, int B) {
     L.ss[u] = take(4 * (size_t)d.cout);
     L.A[u] = (u + 1 < 13 && S.units[u + 1].in_bn) ? take(b * d.hw * d.hw * d.cout) : 0;
     stats = std::max(stats, (size_t)tdx_conv3x3_stat_tiles(B, d.hw, d.hw, d.cin, d.cout) * 2 * d.cout);
-    slabs = std::max(slabs, (size_t)tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout) * 9 *
-                                (size_t)d.cin * d.cout);
+    slabs = std::max(slabs, (size_t)std::max(tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout),
+                                             tdx_conv3x3_wgrad_splits_bf16(B, d.hw, d.hw, d.cin, d.cout)) *
+                                9 * (size_t)d.cin * d.cout);
     ksplit = std::max(ksplit, std::max(tdx_conv3x3_train_scratch_floats(B, d.hw, d.hw, d.cin, d.cout),
                                        tdx_conv3x3_train_scratch_floats(B, d.hw, d.hw, d.cout, d.cin)));
     bnscr = std::max(bnscr, tdx_bn_relu_bwd_scratch_floats((int64_t)b * d.hw * d.hw, d.cout));
@@ -438,19 +439,17 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     pb.wd[i] = u->wpack + u->wd_off[i];
     pb.cout[i] = d.cout; pb.cin[i] = d.cin; pb.cin_real[i] = d.cin_real;
   }
-  if (u->precision == TDX_PREC_BF16) {
-    // bf16 packs live in the same slots (half the bytes); one launch, on the caller's stream
-    int rc = tdx_pack_conv3x3_batch_bf16(&pb, stream);
-    if (rc) return rc;
-  } else if (overlap) {
+  // bf16 packs live in the same slots (half the bytes)
+  auto pack = u->precision == TDX_PREC_BF16 ? tdx_pack_conv3x3_batch_bf16 : tdx_pack_conv3x3_batch;
+  if (overlap) {
     // head now; the tail is launched by pack_tail() once the main stream has MFMA work in flight
     // (beside the tiny kernels at the start of a step it only slowed them down)
     TdxPackBatch head = pb;
     head.count = 2;
-    int rc = tdx_pack_conv3x3_batch(&head, stream);
+    int rc = pack(&head, stream);
     if (rc) return rc;
   } else {
-    int rc = tdx_pack_conv3x3_batch(&pb, stream);
+    int rc = pack(&pb, stream);
     if (rc) return rc;
   }
   for (int i = 0; i < 13; ++i) {
@@ -489,7 +488,8 @@ static int pack_tail(tdx_unet* u, const void* const* params, tdx_stream_t stream
   }
   TDX_HIP(hipEventRecord(u->ev_fork, to_stream(stream)));
   TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-  int rc = tdx_pack_conv3x3_batch(&tail, reinterpret_cast<tdx_stream_t>(u->side));
+  auto pack = u->precision == TDX_PREC_BF16 ? tdx_pack_conv3x3_batch_bf16 : tdx_pack_conv3x3_batch;
+  int rc = pack(&tail, reinterpret_cast<tdx_stream_t>(u->side));
   if (rc) return rc;
   TDX_HIP(hipEventRecord(u->ev_pack, u->side));
   return 0;
@@ -539,7 +539,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const float* cond_emb = u->kind == 1 ? static_cast<const float*>(cond) : nullptr;
 
   const bool bf16 = u->precision == TDX_PREC_BF16;
-  if (!infer) RC(pack_impl(u, params, nullptr, stream, !bf16));  // weights change every step
+  if (!infer) RC(pack_impl(u, params, nullptr, stream, true));  // weights change every step
   else if (!u->packed) RC(pack_impl(u, params, buffers, stream));
   if (!infer) {
     // keep the inputs for backward (caller tensors may be gone by then)
@@ -638,10 +638,10 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
 
   // encoder: two units per level, then 2x2 max-pool of relu(bn(.))
   RC(run_unit(0, ws + L.x0));
-  if (!infer && !bf16) RC(pack_tail(u, params, stream));  // beside unit 1's convolution
+  if (!infer) RC(pack_tail(u, params, stream));  // beside unit 1's convolution
   for (int k = 0; k < 3; ++k) {
     const int ua = 2 * k, ub = 2 * k + 1;
-    if (k == 1 && !infer && !bf16) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
+    if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
     if (k > 0) RC(run_unit(ua, ws + L.ep[k - 1]));
     RC(run_unit(ub, ws + L.Y[ua]));
     if (!infer) {
@@ -800,8 +800,9 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     TDX_HIP(hipEventRecord(u->ev_w[i], wst));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_w[i], 0));
     RC(tdx_conv3x3_wgrad_reduce_pad(slab, G[TDX_P_UNIT0 + 4 * i],
-                                    tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout), d.cout, d.cin,
-                                    d.cin_real, reinterpret_cast<tdx_stream_t>(u->side2)));
+                                    bf16 ? tdx_conv3x3_wgrad_splits_bf16(B, d.hw, d.hw, d.cin, d.cout)
+                                         : tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout),
+                                    d.cout, d.cin, d.cin_real, reinterpret_cast<tdx_stream_t>(u->side2)));
     TDX_HIP(hipEventRecord(u->ev_red[i], u->side2));
     u->red_pending[i] = true;
     GBuf* gbuf = find(g);
