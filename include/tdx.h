@@ -137,6 +137,24 @@ int tdx_pack_conv3x3(const float* w_oihw, float* w_fwd, float* w_dgrad, int cout
 #define TDX_CONV_OUT_BNRELU 2  /* epilogue: out = relu((acc+bias)*out_scale+out_shift)  (inference) */
 #define TDX_CONV_OUT_STATS 4   /* epilogue: also emit per-tile per-channel (sum, sumsq) partials */
 
+/* The two boundary convolutions (diffusion.py:28 initial_conv / :98 final_conv, applied at :116 and :160;
+ * conditional_diffusion_laion.py:244, 296), on the fp32 MFMA with the thin side gathered from NCHW:
+ *   initial_conv  x (B,cin,H,W) NCHW, w (cout,cin,3,3), bias (cout) -> out (B,H,W,64) channels-last; channels
+ *                 >= cout are written as zeros.  (cin, cout) = (1, 64) MNIST | (4, 32) LAION latents.
+ *   final_conv    in (B,H,W,64) channels-last, w (cout,64,3,3), bias (cout) -> out (B,cout,H,W) NCHW; cout = 1 | 4.
+ * backward: g_out in the forward output's layout; dw / db in the parameter's layout; the input gradient of
+ * final_conv (g_in, channels-last) - initial_conv's input is the data, it has none.  scratch:
+ * tdx_edge_conv_wgrad_scratch_floats(B,H,W) floats (consumed).  W >= 4.  Other shapes: TDX_E_SHAPE. */
+size_t tdx_edge_conv_wgrad_scratch_floats(int B, int H, int W);
+int tdx_initial_conv_forward(const float* x, const float* w, const float* bias, float* out, int B, int H, int W,
+                             int cin, int cout, tdx_stream_t stream);
+int tdx_initial_conv_backward(const float* x, const float* g_out, float* dw, float* db, float* scratch, int B,
+                              int H, int W, int cin, int cout, tdx_stream_t stream);
+int tdx_final_conv_forward(const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
+                           int cout, tdx_stream_t stream);
+int tdx_final_conv_backward(const float* in, const float* g_out, const float* w, float* g_in, float* dw, float* db,
+                            float* scratch, int B, int H, int W, int cout, tdx_stream_t stream);
+
 /* 3x3, pad 1, stride 1 convolution as an implicit GEMM on fp32 MFMA
  * (nn.Conv2d(cin,cout,3,padding=1), diffusion.py:28-98), NHWC.
  *   in  (B,H,W,cin)  wpk [cout][9][cin]  bias (cout) or NULL  out (B,H,W,cout)

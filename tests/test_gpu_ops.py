@@ -571,3 +571,59 @@ def test_time_mlp_fwd_bwd(tdx, cond):
                                        scratch.data_ptr(), B, ncls if cond else 0, stream()))
     for k, v in P.items():
         assert rel_err(gd[k], v.grad) < 1e-5, k
+
+
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 28, 1, 64), (2, 32, 4, 32), (37, 28, 1, 64), (5, 64, 4, 32), (21, 7, 1, 64),
+                                          (4, 9, 4, 32)])
+def test_initial_conv_fwd_bwd(tdx, B, H, cin, cout):
+    """diffusion.py:28 / conditional_diffusion_laion.py:244 on the MFMA (thin operand gathered from NCHW): forward and
+    the weight / bias gradients against F.conv2d; pixel counts that are not multiples of the 128-pixel forward
+    tile or of the 512-pixel gradient chunk, odd image sizes."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.3).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    gout = torch.randn(B, H, H, 64, generator=g)   # all 64 stored channels carry a gradient; only `cout` are real
+    ref.backward(nchw(gout)[:, :cout].double())
+    out = torch.full((B, H, H, 64), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_initial_conv_forward(dev(x).data_ptr(), dev(w.detach()).data_ptr(), dev(b.detach()).data_ptr(),
+                                               out.data_ptr(), B, H, H, cin, cout, stream()))
+    got = nchw(out)
+    assert rel_err(got[:, :cout], ref.detach()) < 2e-6
+    assert bool((got[:, cout:] == 0).all())
+    scratch = torch.full((tdx.lib.tdx_edge_conv_wgrad_scratch_floats(B, H, H),), float("nan"), device="cuda")
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_initial_conv_backward(dev(x).data_ptr(), dev(gout).data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                scratch.data_ptr(), B, H, H, cin, cout, stream()))
+    assert rel_err(dw, w.grad) < 3e-6 and rel_err(db, b.grad) < 3e-6
+    assert tdx.lib.tdx_initial_conv_forward(dev(x).data_ptr(), dev(w.detach()).data_ptr(), None, out.data_ptr(), B, H, H,
+                                            2, 64, stream()) != 0
+
+
+@pytest.mark.parametrize("B,H,cout", [(3, 28, 1), (2, 32, 4), (37, 28, 1), (5, 64, 4), (21, 7, 1), (4, 9, 4)])
+def test_final_conv_fwd_bwd(tdx, B, H, cout):
+    """diffusion.py:98 / conditional_diffusion_laion.py:296: forward (NCHW out), input gradient (mirrored taps on
+    the MFMA), weight and bias gradients against F.conv2d."""
+    g = torch.Generator().manual_seed(B * 100 + H + 7)
+    x = torch.randn(B, 64, H, H, generator=g, requires_grad=True)
+    w = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    gout = torch.randn(B, cout, H, H, generator=g)
+    ref.backward(gout.double())
+    xin = dev(nhwc(x.detach()))
+    out = torch.full((B, cout, H, H), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_final_conv_forward(xin.data_ptr(), dev(w.detach()).data_ptr(), dev(b.detach()).data_ptr(),
+                                             out.data_ptr(), B, H, H, cout, stream()))
+    assert rel_err(out, ref.detach()) < 2e-6
+    scratch = torch.full((tdx.lib.tdx_edge_conv_wgrad_scratch_floats(B, H, H),), float("nan"), device="cuda")
+    gin = torch.full((B, H, H, 64), float("nan"), device="cuda")
+    dw = torch.full((cout, 64, 3, 3), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_final_conv_backward(xin.data_ptr(), dev(gout).data_ptr(), dev(w.detach()).data_ptr(),
+                                              gin.data_ptr(), dw.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, H, H,
+                                              cout, stream()))
+    assert rel_err(nchw(gin), x.grad) < 3e-6
+    assert rel_err(dw, w.grad) < 3e-6 and rel_err(db, b.grad) < 3e-6

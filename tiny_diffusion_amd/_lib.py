@@ -68,6 +68,13 @@ _SIGS = {
     "tdx_adam_clip_scratch_bytes": (C.c_size_t, []),
     "tdx_adam_step_clip": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_int, C.c_float, C.c_float, _ptr, _ptr, _ptr]),
+    "tdx_edge_conv_wgrad_scratch_floats": (C.c_size_t, [C.c_int] * 3),
+    "tdx_initial_conv_forward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_initial_conv_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            _ptr]),
+    "tdx_final_conv_forward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, _ptr]),
+    "tdx_final_conv_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          _ptr]),
     "tdx_pack_conv3x3": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_conv3x3_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),

@@ -439,3 +439,32 @@ int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, fl
   TDX_CHECK_LAUNCH();
   return reduce_partials2(partial, dw, db, cout * 576, nblk, SMALLP_W, cout * 576 + cout, st);
 }
+
+// ------------------------------------------------------------------ C ABI (the boundary convolutions on their own)
+extern "C" size_t tdx_edge_conv_wgrad_scratch_floats(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)tdx_small_conv_wgrad_blocks(B, H, W) * SMALLP_W;
+}
+extern "C" int tdx_initial_conv_forward(const float* x, const float* w, const float* bias, float* out, int B, int H,
+                                        int W, int cin, int cout, tdx_stream_t stream) {
+  if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  return tdx_initial_conv_fwd(x, w, bias, out, B, H, W, cin, cout, to_stream(stream));
+}
+extern "C" int tdx_initial_conv_backward(const float* x, const float* g_out, float* dw, float* db, float* scratch,
+                                         int B, int H, int W, int cin, int cout, tdx_stream_t stream) {
+  if (!x || !g_out || !dw || !db || !scratch || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  return tdx_initial_conv_wgrad(x, g_out, scratch, dw, db, B, H, W, cin, cout, to_stream(stream));
+}
+extern "C" int tdx_final_conv_forward(const float* in, const float* w, const float* bias, float* out, int B, int H,
+                                      int W, int cout, tdx_stream_t stream) {
+  if (!in || !w || !bias || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  return tdx_final_conv_fwd(in, w, bias, out, B, H, W, cout, to_stream(stream));
+}
+extern "C" int tdx_final_conv_backward(const float* in, const float* g_out, const float* w, float* g_in, float* dw,
+                                       float* db, float* scratch, int B, int H, int W, int cout,
+                                       tdx_stream_t stream) {
+  if (!in || !g_out || !w || !g_in || !dw || !db || !scratch || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  const int rc = tdx_final_conv_dgrad(g_out, w, g_in, B, H, W, cout, to_stream(stream));
+  if (rc) return rc;
+  return tdx_final_conv_wgrad(in, g_out, scratch, dw, db, B, H, W, cout, to_stream(stream));
+}
