@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TDX_VERSION 200 /* 0.2.0: tdx_time_mlp_bwd scratch (3*256+1)*B floats; new exports */
+#define TDX_VERSION 210 /* 0.2.1: additions only since 0.2.0 (boundary convolutions, tdx_conv3x3_fwd_train, bf16 split plan, stream schedule); tdx_time_mlp_bwd scratch grew in 0.2.0 */
 
 #define TDX_E_BADARG (-1)   /* null pointer, size <= 0, batch > plan capacity ... */
 #define TDX_E_SHAPE (-2)    /* shape the kernel family does not cover */
