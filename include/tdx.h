@@ -491,6 +491,7 @@ int tdx_tune_set(const char* key, int value);
 /* Diagnostics (tools/gpu_stage6_diag.py): device buffer that the instrumented variant of the time-path
  * kernel (knob "time_l1_impl" = 2) records its loads into; NULL disables it. */
 int tdx_diag_set_buffer(void* device_buffer);
+int tdx_diag_conv_occupancy(int tile);  /* resident workgroups per CU of the forward kernel of tile bm*1000+bn */
 
 /* Peak probes used by bench.py for measured roofline denominators. */
 int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream);

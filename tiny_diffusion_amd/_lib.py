@@ -87,6 +87,7 @@ _SIGS = {
     "tdx_conv3x3_stat_tiles": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_stat_tile_rows": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
+    "tdx_diag_conv_occupancy": (C.c_int, [C.c_int]),
     "tdx_conv3x3_wgrad_splits_bf16": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_shape_ok": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_tile_shape": (C.c_int, [C.c_int] * 6),

@@ -402,6 +402,7 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                // [2][BM][32]
   float* Bs = smem + 2 * BM * BK;  // [2][BN][32]
+  const unsigned long long t_entry = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;  // diagnostics only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -532,6 +533,8 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
     o[0] = c1 - c0; o[1] = r1 - r0;                      // main loop: cycles, 10-ns ticks
     o[2] = r0; o[3] = r1; o[4] = __builtin_amdgcn_s_memrealtime();  // absolute: loop start, loop end, epilogue end
     o[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf;  // XCC id
+    o[6] = t_entry;                                                       // first instruction of the workgroup
+    o[7] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));          // HW_REG_HW_ID (wave, SIMD, CU, SH, SE ids)
   }
 #endif
 }
@@ -665,6 +668,19 @@ extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* d
   // the forward kernel on dy with the mirrored, channel-swapped pack: its "cin" is this layer's cout
   return tdx_conv3x3_fwd(dy, w_dgrad, nullptr, dx, B, H, W, cout, cin, 0, nullptr, nullptr, nullptr, nullptr,
                          nullptr, stream);
+}
+
+// diagnostics: resident workgroups per CU the runtime computes for the LDS-DMA forward kernel of a tile
+// (bm*1000 + bn; training epilogue) and for the weight-gradient kernel (negative argument)
+extern "C" int tdx_diag_conv_occupancy(int tile) {
+  int n = -1;
+  hipError_t e = hipErrorInvalidValue;
+#define OCC(K, LDS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(K), 256, LDS)
+  if (tile == 64064) OCC((conv3x3_igemm_dma_kernel<64, 64, EPI_STATS>), (size_t)2 * 128 * BK * 4);
+  else if (tile == 128064) OCC((conv3x3_igemm_dma_kernel<128, 64, EPI_STATS>), (size_t)2 * 192 * BK * 4);
+  else if (tile == 128128) OCC((conv3x3_igemm_dma_kernel<128, 128, EPI_STATS>), (size_t)2 * 256 * BK * 4);
+#undef OCC
+  return e == hipSuccess ? n : -(int)e;
 }
 
 extern "C" int tdx_tune_set(const char* key, int value) {
