@@ -661,6 +661,9 @@ static int g_splitk_train = 1;       // training convolutions of latency-bound s
 static int g_splitk_train_t64 = 1024;   // ... when the 64x64 grid has fewer tiles than this
 static int g_splitk_train_target = 1536;  // ... into about this many workgroups
 static int g_splitk_train_any = 0;      // 1: also shapes whose picked tile is 128x128
+static int g_wgrad_plan = 1;          // 0: round-1 targets; 1: the same, split count rounded down to two whole rounds of slots;
+                                      // 2: tile and rounds by a cost model (experiments: best isolated, worse inside the step)
+static int g_wgrad_rounds = 0;        // experiments: force that many rounds in pick_wgrad (0: cheapest by its cost model)
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
@@ -709,6 +712,8 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
   if (!strcmp(key, "conv_stamp")) { g_conv_stamp = value; g_tdx_probe_stamp = value; return 0; }
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
+  if (!strcmp(key, "wgrad_plan")) { g_wgrad_plan = value; return 0; }
+  if (!strcmp(key, "wgrad_rounds")) { g_wgrad_rounds = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }
   if (!strcmp(key, "wgrad_target")) { g_wgrad_target = value > 0 ? value : 2048; return 0; }
   if (!strcmp(key, "wgrad_target_big")) { g_wgrad_target_big = value > 0 ? value : 0; return 0; }
@@ -1391,7 +1396,17 @@ struct WgradCfg {
   int bm, bn, splits, chunk;
 };
 
-static WgradCfg pick_wgrad(int64_t M, int cin, int cout, bool bf16 = false) {
+// Workgroups of a kernel that one CU holds: LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128), so
+// the 32 KB of a 64x64 tile cost 33,280 bytes and FOUR fit, not the five that 160 / 32 (and
+// hipOccupancyMaxActiveBlocksPerMultiprocessor) promise - measured with per-workgroup HW_ID stamps: every CU
+// peaks at exactly 4 (tools/gpu_wg_lifetime.py).  48 KB -> 3, 64 KB -> 2.
+static int lds_slots_per_cu(int lds_bytes) {
+  const int alloc = (lds_bytes + 1279) / 1280 * 1280;
+  const int n = 163840 / alloc;
+  return n < 1 ? 1 : n > 8 ? 8 : n;
+}
+
+static WgradCfg pick_wgrad_legacy(int64_t M, int cin, int cout, bool bf16) {
   WgradCfg c;
   c.bm = (cout % 128 == 0) ? 128 : 64;
   c.bn = (cin % 128 == 0) ? 128 : 64;
@@ -1404,6 +1419,16 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout, bool bf16 = false) {
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
   const int target = (c.bm == 128 && c.bn == 128 && g_wgrad_target_big > 0) ? g_wgrad_target_big : g_wgrad_target;
   int64_t s = (target + tiles - 1) / tiles;
+  if (!bf16 && g_wgrad_plan == 1 && c.bm == c.bn) {
+    // Both targets are two rounds of the chip's workgroup slots (64x64: 4 per CU, 128x128: 2; lds_slots_per_cu),
+    // but rounding the split count UP put most layers a few workgroups ABOVE two rounds (2052 on 1024 slots,
+    // 1044 on 512), i.e. into a third round for 4 of them: isolated, 554 -> 463 us (256 -> 256 at 14x14),
+    // 744 -> 608 (512 -> 128 at 16x16), 201 -> 165 (128 -> 128 at 16x16).  Round DOWN where the split is fine
+    // enough for that to matter.  (Inside the step, where this kernel shares the CUs with the input-gradient
+    // GEMM, it is neutral; ONE round - fewest slabs - is 5 % slower there: nothing left to rebalance with.)
+    const int64_t two_rounds = 2 * 256 * (int64_t)lds_slots_per_cu(2 * 32 * (c.bm + c.bn) * 4);
+    if (two_rounds / tiles >= 8) s = two_rounds / tiles;
+  }
   int64_t smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
@@ -1413,6 +1438,41 @@ static WgradCfg pick_wgrad(int64_t M, int cin, int cout, bool bf16 = false) {
   c.splits = (int)s;
   c.chunk = (int)chunk;
   return c;
+}
+
+// Experimental plan (knob wgrad_plan = 2): for every tile shape the layer's channels allow and 1..4 rounds of
+// workgroup slots, the largest split count whose workgroups fit those rounds; cost = GEMM time at the fill of
+// its rounds + slab write and re-read.  It picks one round almost everywhere (fewest slabs), which is the best
+// ISOLATED choice for most layers and 5 % slower inside the step (16.3 vs 15.6 ms): one long workgroup per slot
+// cannot be rebalanced against the input-gradient GEMM sharing the CUs.
+static WgradCfg pick_wgrad(int64_t M, int cin, int cout, bool bf16 = false) {
+  if (bf16 || g_wgrad_plan != 2) return pick_wgrad_legacy(M, cin, cout, bf16);
+  const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  const double flops = 2.0 * (double)M * 9.0 * cin * cout;
+  const int64_t smax = (M + 255) / 256;
+  WgradCfg best = pick_wgrad_legacy(M, cin, cout, false);
+  double best_t = 1e30;
+  for (int i = 0; i < 4; ++i) {
+    const int bm = cand[i][0], bn = cand[i][1];
+    if (cout % bm || cin % bn) continue;
+    const int64_t tiles9 = (int64_t)(cout / bm) * (cin / bn) * 9;
+    const int64_t slots = 256 * (int64_t)lds_slots_per_cu(2 * 32 * (bm + bn) * 4);
+    const double tile_eff = (bm == 128 && bn == 128) ? 1.0 : (bm == 64 && bn == 64) ? 0.94 : 0.97;
+    for (int r = 1; r <= 4; ++r) {
+      if (g_wgrad_rounds > 0 && r != g_wgrad_rounds) continue;
+      int64_t s = r * slots / tiles9;
+      if (s > smax) s = smax;
+      if (s < 1) continue;
+      int64_t chunk = ((M + s - 1) / s + 31) / 32 * 32;
+      s = (M + chunk - 1) / chunk;
+      const int64_t wgs = tiles9 * s, rounds = (wgs + slots - 1) / slots;
+      const double fill = (double)wgs / (double)(rounds * slots);
+      const double t = flops / (157.3e12 * 0.85 * tile_eff * fill) +
+                       (double)s * cout * cin * 9.0 * 4.0 * 2.0 / 4.0e12 + (chunk < 512 ? 2e-6 : 0.0);
+      if (t < best_t) { best_t = t; best.bm = bm; best.bn = bn; best.splits = (int)s; best.chunk = (int)chunk; }
+    }
+  }
+  return best;
 }
 
 // which tile a shape resolves to (tests assert that every template is exercised):
