@@ -74,13 +74,24 @@ def conv_roofline(B: int, reps: int = 5):
         ish = torch.randn(cin, device=dev) * 0.1
         sc_p, sh_p = (isc.data_ptr(), ish.data_ptr()) if in_bn else (None, None)
 
+        # raw-input launches go through the entry point the training step uses (tdx_conv3x3_fwd_train: shapes
+        # whose tiles do not fill whole rounds of workgroup slots K-slice the remainder and add one small
+        # reduction launch, which is inside the timed region)
+        need = max(lib.tdx_conv3x3_train_scratch_floats(B, H, H, cin, cout),
+                   lib.tdx_conv3x3_train_scratch_floats(B, H, H, cout, cin))
+        scratch = torch.empty(max(need, 1), device=dev)
+
         def fwd():
-            check(lib.tdx_conv3x3_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, cin,
-                                      cout, 4 | in_bn, sc_p, sh_p, None, None, stats.data_ptr(), st))
+            if in_bn:
+                check(lib.tdx_conv3x3_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, cin,
+                                          cout, 4 | in_bn, sc_p, sh_p, None, None, stats.data_ptr(), st))
+            else:
+                check(lib.tdx_conv3x3_fwd_train(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H,
+                                                cin, cout, 4, stats.data_ptr(), scratch.data_ptr(), need, st))
 
         def dgrad():
-            check(lib.tdx_conv3x3_fwd(dy.data_ptr(), wf.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
-                                      None, None, None, None, None, st))
+            check(lib.tdx_conv3x3_fwd_train(dy.data_ptr(), wf.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                            None, scratch.data_ptr(), need, st))
 
         def wgrad():
             check(lib.tdx_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, in_bn,

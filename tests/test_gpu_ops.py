@@ -250,7 +250,9 @@ def test_conv3x3_fwd_splitk_inference(tdx, B, H, cin, cout):
 
 
 @pytest.mark.parametrize("B,H,cin,cout,split", [(256, 4, 512, 512, True), (64, 4, 256, 256, True), (37, 4, 512, 512, True),
-                                                (256, 8, 256, 256, False), (9, 7, 128, 512, True)])
+                                                (256, 8, 256, 256, False), (9, 7, 128, 512, True),
+                                                # hybrid launches: whole rounds of tiles + K-slices of the last row tiles
+                                                (256, 28, 64, 128, True), (251, 14, 128, 256, True), (256, 32, 64, 64, False)])
 def test_conv3x3_fwd_train_splitk(tdx, B, H, cin, cout, split):
     """training convolutions of latency-bound shapes (the UNet bottleneck at the benchmarked batch): K split over
     64x64 workgroups, then ONE launch reduces the partials in a fixed order, adds the bias and writes the same

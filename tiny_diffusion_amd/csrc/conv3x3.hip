@@ -412,7 +412,13 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
   // Workgroup id -> tile, XCD-aware: ids are dealt round-robin over the 8 XCDs, so the tilesN
   // column tiles of one row tile (which read the same input rows) are given ids that differ by
   // multiples of 8 inside a block of 8*tilesN consecutive ids: same XCD, same L2, close in time.
-  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  int vb = blockIdx.x, hyb_slice = -1;
+  if (!SPLITK && a.hyb_sp > 0 && vb >= a.hyb_full) {  // K-slice of one of the last row tiles (hybrid launch)
+    const int q = vb - a.hyb_full;
+    hyb_slice = q % a.hyb_sp;
+    vb = a.hyb_full + q / a.hyb_sp;
+  }
+  const int xb = vb / (8 * a.tilesN), xr = vb % (8 * a.tilesN);
   const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
   if (tile_m * BM >= a.M) return;  // grid is padded to a multiple of 8 row tiles
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -462,8 +468,8 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
 
   const int nk_total = 9 * (a.Cin / BK);
-  const int kt0 = SPLITK ? (int)blockIdx.y * a.kt_per_split : 0;
-  const int nk = SPLITK ? min(a.kt_per_split, nk_total - kt0) : nk_total;
+  const int kt0 = SPLITK ? (int)blockIdx.y * a.kt_per_split : hyb_slice >= 0 ? hyb_slice * a.kt_per_split : 0;
+  const int nk = (SPLITK || hyb_slice >= 0) ? min(a.kt_per_split, nk_total - kt0) : nk_total;
 
   auto dma_tile = [&](int kt, int buf) {
     const int kn = kt0 + min(kt, nk - 1);
@@ -527,6 +533,14 @@ conv3x3_igemm_dma_kernel(ConvArgs a) {
   }
   unsigned long long c1 = 0, r1 = 0;
   if (a.stamps) { c1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime(); }
+  if (!SPLITK && hyb_slice >= 0) {
+    // raw partial of this K-slice: the split-K epilogue on a view of the remainder rows
+    ConvArgs b = a;
+    b.out = a.hyb_scratch + ((ptrdiff_t)hyb_slice * (a.M - a.hyb_row0) - a.hyb_row0) * (ptrdiff_t)a.Cout;
+    b.tile_counters = nullptr;
+    conv_epilogue<BM, BN, EPI_PLAIN, true>(b, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
+    return;
+  }
   conv_epilogue<BM, BN, EPI, SPLITK>(a, acc, smem, tile_m, m0, n0, wm, wn, l31, half, tid);
   if (a.stamps && tid == 0) {   // in-kernel clock = d(shader cycles) / d(100 MHz ticks) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
     unsigned long long* o = a.stamps + 8 * blockIdx.x;
@@ -574,15 +588,19 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
 template <int TILE_ROWS>
 __global__ void __launch_bounds__(256)
 splitk_reduce_stats_kernel(const float* __restrict__ partial, int splits, int M, int cout,
-                           const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ stats) {
+                           const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ stats,
+                           int row0) {
+  // row0 > 0 (hybrid launch): only rows [row0, M) were split; partial holds [splits][M - row0][cout]
   constexpr int RJ = TILE_ROWS / 16;
   __shared__ float red[16][64];
   __shared__ float tsum[64];
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int n0 = blockIdx.y * 64, col = n0 + c4 * 4;
-  const int m0 = blockIdx.x * TILE_ROWS;
+  const int m0 = row0 + blockIdx.x * TILE_ROWS;
   const int rows_valid = min(TILE_ROWS, M - m0);
-  const size_t slab = (size_t)M * cout;
+  const size_t slab = (size_t)(M - row0) * cout;
+  const int stile = m0 / TILE_ROWS;
+  partial -= (size_t)row0 * cout;
   const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 v[RJ];
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -607,7 +625,7 @@ splitk_reduce_stats_kernel(const float* __restrict__ partial, int splits, int M,
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
     tsum[threadIdx.x] = t;
-    stats[((size_t)blockIdx.x * 2 + 0) * cout + n0 + threadIdx.x] = t;
+    stats[((size_t)stile * 2 + 0) * cout + n0 + threadIdx.x] = t;
   }
   __syncthreads();
   const float inv_n = 1.0f / (float)rows_valid;
@@ -626,7 +644,7 @@ splitk_reduce_stats_kernel(const float* __restrict__ partial, int splits, int M,
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-    stats[((size_t)blockIdx.x * 2 + 1) * cout + n0 + threadIdx.x] = t;
+    stats[((size_t)stile * 2 + 1) * cout + n0 + threadIdx.x] = t;
   }
 }
 
@@ -634,6 +652,16 @@ splitk_reduce_stats_kernel(const float* __restrict__ partial, int splits, int M,
 struct TileCfg {
   int bm, bn;
 };
+
+// Workgroups of a kernel that one CU holds: LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128), so
+// the 32 KB of a 64x64 tile cost 33,280 bytes and FOUR fit, not the five that 160 / 32 (and
+// hipOccupancyMaxActiveBlocksPerMultiprocessor) promise - measured with per-workgroup HW_ID stamps: every CU
+// peaks at exactly 4 (tools/gpu_wg_lifetime.py).  48 KB -> 3, 64 KB -> 2.
+static int lds_slots_per_cu(int lds_bytes) {
+  const int alloc = (lds_bytes + 1279) / 1280 * 1280;
+  const int n = 163840 / alloc;
+  return n < 1 ? 1 : n > 8 ? 8 : n;
+}
 
 // tuning knobs (tdx_tune_set): 0 = heuristic
 static int g_force_tile = 0;          // 1: 128x128, 2: 128x64, 3: 64x64
@@ -653,6 +681,7 @@ static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 static int g_wgrad_target_big = 1024; // the same for 128x128 tiles (0: g_wgrad_target): at most two of them fit a
                                       // CU (64 KiB of LDS each), so fewer, longer workgroups halve the slab traffic
+static int g_conv_hybrid = 1;        // training convolutions: K-slice the tiles beyond the last whole round (plan_hybrid)
 static int g_splitk_fused = 0;       // 1: the last-arriving workgroup of a tile reduces the split-K partials (conv_epilogue).
                                       // OFF: the device-scope release/acquire it needs (splits of a tile sit behind
                                       // different XCDs' L2s: buffer_wbl2 / buffer_inv) costs ~68 us per convolution,
@@ -700,6 +729,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "conv_hybrid")) { g_conv_hybrid = value != 0; return 0; }
   if (!strcmp(key, "splitk_fused")) { g_splitk_fused = value != 0; return 0; }
   if (!strcmp(key, "splitk_train")) { g_splitk_train = value != 0; return 0; }
   if (!strcmp(key, "splitk_train_t64")) { g_splitk_train_t64 = value > 0 ? value : 1024; return 0; }
@@ -840,11 +870,13 @@ static int plan_splitk_train(int64_t M, int cin, int cout, int* kt_per_split, si
   return (nk + per - 1) / per;
 }
 
+static bool plan_hybrid(int64_t M, int cin, int cout, TileCfg c, struct HybridPlan* h);
+static size_t hybrid_scratch_floats(int64_t M, int cin, int cout);
 extern "C" size_t tdx_conv3x3_train_scratch_floats(int B, int H, int W, int cin, int cout) {
   int per;
   const int64_t M = (int64_t)B * H * W;
   const int s = plan_splitk_train(M, cin, cout, &per);
-  return s > 1 ? (size_t)s * M * cout : 0;
+  return s > 1 ? (size_t)s * M * cout : hybrid_scratch_floats(M, cin, cout);
 }
 
 // raw-input (LDS-DMA) 64x64 split-K launch, then the training reduction: statistics in tiles of the rows the
@@ -861,14 +893,86 @@ static int launch_splitk_train(ConvArgs a, int splits, int per, float* scratch, 
   if (a.stats) {
     dim3 rg(cdiv(a.M, stat_rows), a.Cout / 64);
     if (stat_rows == 128)
-      splitk_reduce_stats_kernel<128><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats);
+      splitk_reduce_stats_kernel<128><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats, 0);
     else
-      splitk_reduce_stats_kernel<64><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats);
+      splitk_reduce_stats_kernel<64><<<rg, 256, 0, st>>>(scratch, splits, a.M, a.Cout, a.bias, final_out, a.stats, 0);
   } else {
     const int64_t n4 = (int64_t)a.M * a.Cout / 4;
     int rg = (int)((n4 + 255) / 256);
     if (rg > 2048) rg = 2048;
     splitk_reduce_kernel<false><<<rg, 256, 0, st>>>(scratch, splits, n4, a.Cout, a.bias, nullptr, nullptr, final_out);
+  }
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// Hybrid launch of a TRAINING convolution whose tiles do not fill a whole number of rounds of the chip's workgroup
+// slots (256 CUs x lds_slots_per_cu): 6272 tiles of 64x64 are 6.125 rounds of 1024 slots, 3136 are 3.06, 1568 are
+// 1.53 - the encoder layers of the UNet at B = 256 ran at 104-124 TFLOP/s against 128-137 for the decoder layers
+// whose grids happen to divide, whatever tile was forced.  The tiles of the whole rounds run as usual; the rest
+// (the LAST row tiles) are cut along K into `sp` slices per tile - workgroups 1/sp as long, which the dispatcher
+// packs into the slots as they free up - in the SAME launch, and one small launch sums their partials (with the
+// BatchNorm partials of those rows, or plainly for the input gradient).  Only the remainder rows pay partial traffic.
+struct HybridPlan {
+  int full_blocks, sp, per, row0;
+  size_t scratch_floats;
+};
+static bool plan_hybrid(int64_t M, int cin, int cout, TileCfg c, HybridPlan* h) {
+  // 64x64 tiles only: measured isolated at B = 256, us: 256->256 @14 484 -> 466, 512->512 @7 504 -> 463, 128->256 @14
+  // and 256->512 @7 261 -> 254; the 28x28 layers do not move (530: they are held back by their 103 MB inputs coming
+  // from HBM - 460 back to back out of the MALL - not by the 0.125 of a round they spill), and the 128x64-tile
+  // decoder layers lose 4-10 % (their last round is two thirds full).  Inside the step the total is unchanged.
+  if (!g_conv_hybrid || c.bm != 64 || c.bn != 64) return false;
+  const int64_t tilesM = (M + c.bm - 1) / c.bm, tilesN = cout / c.bn, group = 8 * tilesN;
+  const int64_t S = 256 * (int64_t)lds_slots_per_cu(2 * (c.bm + c.bn) * BK * 4);
+  const int64_t T = tilesM * tilesN;
+  if (T <= S) return false;                       // one (partial) round: the dispatcher has nothing to balance
+  const int64_t G_full = (T / S) * S / group;     // whole rounds, in groups of 8 row tiles x all column tiles
+  const int64_t rem_row_tiles = tilesM - G_full * 8;
+  if (rem_row_tiles <= 0) return false;
+  const int64_t Trem = rem_row_tiles * tilesN;
+  if (4 * Trem > 3 * S) return false;             // the last round is nearly full as it is
+  const int nk = 9 * (cin / BK);
+  int best_sp = 0;
+  double best = 0.85;                             // fraction of a round the remainder may cost; unsplit it costs ~1
+  for (int sp = 2; sp <= 16 && sp <= nk / 4; ++sp) {
+    const double cost = (double)((Trem * sp + S - 1) / S) / sp + 0.01 * sp;   // + partial traffic
+    if (cost < best) { best = cost; best_sp = sp; }
+  }
+  if (!best_sp) return false;
+  h->per = (nk + best_sp - 1) / best_sp;
+  h->sp = (nk + h->per - 1) / h->per;
+  h->full_blocks = (int)(G_full * group);
+  h->row0 = (int)(G_full * 8 * c.bm);
+  h->scratch_floats = (size_t)h->sp * (size_t)(M - h->row0) * cout;
+  return true;
+}
+
+static size_t hybrid_scratch_floats(int64_t M, int cin, int cout) {
+  HybridPlan h;
+  return plan_hybrid(M, cin, cout, pick_tile(M, cout), &h) ? h.scratch_floats : 0;
+}
+
+template <int BM, int BN>
+static int launch_hybrid(ConvArgs a, const HybridPlan& h, float* scratch, bool stats, hipStream_t st) {
+  a.hyb_full = h.full_blocks; a.hyb_sp = h.sp; a.hyb_row0 = h.row0; a.hyb_scratch = scratch;
+  a.kt_per_split = h.per;
+  const int vtot = (cdiv(a.M, BM) + 7) / 8 * 8 * a.tilesN;
+  const int grid = h.full_blocks + (vtot - h.full_blocks) * h.sp;
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  if (stats) conv3x3_igemm_dma_kernel<BM, BN, EPI_STATS><<<grid, 256, lds, st>>>(a);
+  else conv3x3_igemm_dma_kernel<BM, BN, EPI_PLAIN><<<grid, 256, lds, st>>>(a);
+  TDX_CHECK_LAUNCH();
+  const int rem = a.M - h.row0;
+  if (stats) {
+    dim3 rg(cdiv(rem, BM), a.Cout / 64);
+    splitk_reduce_stats_kernel<BM><<<rg, 256, 0, st>>>(scratch, h.sp, a.M, a.Cout, a.bias, a.out, a.stats, h.row0);
+  } else {
+    const int64_t n4 = (int64_t)rem * a.Cout / 4;
+    int rg = (int)((n4 + 255) / 256);
+    if (rg > 2048) rg = 2048;
+    splitk_reduce_kernel<false><<<rg, 256, 0, st>>>(scratch, h.sp, n4, a.Cout, a.bias, nullptr, nullptr,
+                                                    a.out + (size_t)h.row0 * a.Cout);
   }
   TDX_CHECK_LAUNCH();
   return 0;
@@ -978,6 +1082,13 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
     int per;
     const int splits = plan_splitk_train(M64, cin, cout, &per, scratch_floats);
     if (splits > 1) return launch_splitk_train(a, splits, per, splitk_scratch, c.bm, st);
+    HybridPlan h;
+    if (plan_hybrid(M64, cin, cout, c, &h) && h.scratch_floats <= scratch_floats && !a.stamps) {
+      const bool stats = flags & TDX_CONV_OUT_STATS;
+      if (c.bm == 128 && c.bn == 128) return launch_hybrid<128, 128>(a, h, splitk_scratch, stats, st);
+      if (c.bm == 128 && c.bn == 64) return launch_hybrid<128, 64>(a, h, splitk_scratch, stats, st);
+      return launch_hybrid<64, 64>(a, h, splitk_scratch, stats, st);
+    }
   } else if (splitk_scratch && !(flags & TDX_CONV_OUT_STATS)) {
     int per;
     const int splits = plan_splitk(M64, cin, cout, &per, scratch_floats);
@@ -1395,16 +1506,6 @@ conv3x3_wgrad_dma_kernel(WgradArgs a) {
 struct WgradCfg {
   int bm, bn, splits, chunk;
 };
-
-// Workgroups of a kernel that one CU holds: LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128), so
-// the 32 KB of a 64x64 tile cost 33,280 bytes and FOUR fit, not the five that 160 / 32 (and
-// hipOccupancyMaxActiveBlocksPerMultiprocessor) promise - measured with per-workgroup HW_ID stamps: every CU
-// peaks at exactly 4 (tools/gpu_wg_lifetime.py).  48 KB -> 3, 64 KB -> 2.
-static int lds_slots_per_cu(int lds_bytes) {
-  const int alloc = (lds_bytes + 1279) / 1280 * 1280;
-  const int n = 163840 / alloc;
-  return n < 1 ? 1 : n > 8 ? 8 : n;
-}
 
 static WgradCfg pick_wgrad_legacy(int64_t M, int cin, int cout, bool bf16) {
   WgradCfg c;

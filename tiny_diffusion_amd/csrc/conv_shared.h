@@ -25,6 +25,11 @@ struct ConvArgs {
   // applies bias / BN+ReLU (out_scale) and writes final_out; null = a separate launch reduces
   unsigned* tile_counters;
   float* final_out;
+  // hybrid launch (training, non-split kernels): block ids >= hyb_full are K-SLICES of the last row tiles -
+  // id hyb_full + q is slice q % hyb_sp (kt_per_split K-tiles) of virtual block hyb_full + q / hyb_sp - and write
+  // raw partials to hyb_scratch[slice][row - hyb_row0][Cout]; hyb_sp = 0: off (conv3x3.hip, plan_hybrid)
+  int hyb_full, hyb_sp, hyb_row0;
+  float* hyb_scratch;
   unsigned long long* stamps;  // diagnostics (tools/gpu_clock_probe.py): per workgroup {shader cycles, 100 MHz ticks}
                                // around the main loop; null in every product launch
 };
