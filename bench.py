@@ -708,6 +708,11 @@ def main():
             note("latent MLP leg ...")
             res["latent_mlp"] = latent_extras()
             note("done")
+        elif not args.no_extras and not args.train_only:
+            # N > 1: the kernel-level figure of rank 0's GPU (the other ranks are done; no collective follows)
+            res["roofline"] = roofline_block(PER_GPU_BATCH)
+            res["roofline"]["whole_step_frac"] = round(
+                value / world * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         print(json.dumps(res), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
