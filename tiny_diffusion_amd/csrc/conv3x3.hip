@@ -1059,7 +1059,7 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   ConvArgs a{};
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
-  a.stats = stats_partial;
+  a.stats = (flags & TDX_CONV_OUT_STATS) ? stats_partial : nullptr;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   TileCfg c = pick_tile(M64, cout);
   a.tilesN = cout / c.bn;
