@@ -261,6 +261,16 @@ def test_conv3x3_fwd_train_splitk(tdx, B, H, cin, cout, split):
     ref = F.conv2d(x, w, b, padding=1)
     wf, _ = _pack(tdx, w)
     xin, bd = dev(nhwc(x)), dev(b)
+    hybrid = B * H * H > 16384      # the big shapes exercise the hybrid launch (off by default: knob conv_hybrid)
+    if hybrid:
+        tdx.check(tdx.lib.tdx_tune_set(b"conv_hybrid", 1))
+    try:
+        _fwd_train_checks(tdx, x, w, b, ref, wf, xin, bd, B, H, cin, cout, split)
+    finally:
+        tdx.check(tdx.lib.tdx_tune_set(b"conv_hybrid", 0))
+
+
+def _fwd_train_checks(tdx, x, w, b, ref, wf, xin, bd, B, H, cin, cout, split):
     need = tdx.lib.tdx_conv3x3_train_scratch_floats(B, H, H, cin, cout)
     assert (need > 0) == split
     scratch = torch.full((max(need, 1),), float("nan"), device="cuda")

@@ -681,7 +681,10 @@ static int g_splitk_target = 512;     // ... into about this many workgroups
 static int g_wgrad_target = 2048;     // workgroups aimed at by the wgrad pixel split
 static int g_wgrad_target_big = 1024; // the same for 128x128 tiles (0: g_wgrad_target): at most two of them fit a
                                       // CU (64 KiB of LDS each), so fewer, longer workgroups halve the slab traffic
-static int g_conv_hybrid = 1;        // training convolutions: K-slice the tiles beyond the last whole round (plan_hybrid)
+static int g_conv_hybrid = 0;        // 1: training convolutions K-slice the tiles beyond the last whole round (plan_hybrid).
+                                      // OFF: isolated it gains 1 % on the roofline leg (120.9 -> 121.7 TFLOP/s), inside the step
+                                      // nothing (the reduction launch it adds sits in the forward's dependent chain: 15.53 vs
+                                      // 15.56 ms), and it adds 16 % HBM traffic per launch (221.9 -> 257.7 MB, PMC)
 static int g_splitk_fused = 0;       // 1: the last-arriving workgroup of a tile reduces the split-K partials (conv_epilogue).
                                       // OFF: the device-scope release/acquire it needs (splits of a tile sit behind
                                       // different XCDs' L2s: buffer_wbl2 / buffer_inv) costs ~68 us per convolution,
