@@ -295,7 +295,7 @@ __global__ void lin_dgrad_kernel(const float* __restrict__ g, const float* __res
 // block = 32 columns j x 8 interleaved slices of n
 __global__ void __launch_bounds__(256)
 time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
-                   const float* __restrict__ tf, float* __restrict__ dw1, float* __restrict__ db1,
+                   const float* tf, float* __restrict__ dw1, float* __restrict__ db1,
                    int B, int td) {
   __shared__ float red[2][8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -304,7 +304,10 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
 #pragma unroll 4
   for (int n = sl; n < B; n += 8) {
     const float gp = g_h[(size_t)n * td + j] * silu_grad_f(pre[(size_t)n * td + j]);
-    sw = fmaf(gp, tf[n], sw);
+    // agent-scope load: served by the coherent point, whatever line of this address the XCD's L2 may hold.  The
+    // one unexplained miscompute of this path was exactly ONE 128-byte line of the step indices read wrong by one
+    // workgroup (13 of 400 runs with plain loads of the int64 copy, 0 of 200 with this form)
+    sw = fmaf(gp, __hip_atomic_load(tf + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sw);
     sb += gp;
   }
   red[0][sl][cl] = sw;
@@ -336,6 +339,34 @@ time_l1_bwd_i64_kernel(const float* __restrict__ g_h, const float* __restrict__ 
   for (int n = sl; n < B; n += 8) {
     const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
     sw = fmaf(gp, (float)t[n], sw);
+    sb += gp;
+  }
+  red[0][sl][cl] = sw;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0) {
+    sw = 0.f; sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sw += red[0][k][cl]; sb += red[1][k][cl]; }
+    dw1[j] = sw;
+    db1[j] = sb;
+  }
+}
+// DIAGNOSTIC ONLY (time_l1_impl=3): the first version again, with t read by agent-scope atomic loads (served by
+// the coherent point, not by whatever line this XCD's L2 may hold): if the wrong dW1 is a stale L2 line - the
+// error is exactly 16 consecutive samples = one 128-byte line of t in the clean failures - it cannot recur here.
+__global__ void __launch_bounds__(256)
+time_l1_bwd_i64_coherent_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
+                                const int64_t* t, float* __restrict__ dw1, float* __restrict__ db1, int B) {
+  __shared__ float red[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
+  float sw = 0.f, sb = 0.f;
+#pragma unroll 4
+  for (int n = sl; n < B; n += 8) {
+    const float gp = g_h[(size_t)n * TD + j] * silu_grad_f(pre[(size_t)n * TD + j]);
+    const int64_t tv = __hip_atomic_load(t + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sw = fmaf(gp, (float)tv, sw);
     sb += gp;
   }
   red[0][sl][cl] = sw;
@@ -405,18 +436,28 @@ __global__ void silu_kernel(const float* __restrict__ pre, float* __restrict__ h
 }
 
 // dE[c][j] = sum_{n : y[n] == c} g_emb[n][j]   (nn.Embedding backward, fixed order)
-__global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int64_t* __restrict__ y,
+__global__ void class_emb_bwd_kernel(const float* __restrict__ g_emb, const int64_t* y,
                                      float* __restrict__ de, int B, int ncls, int td) {
+  __shared__ int ys[256];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncls * td) return;
-  const int c = idx / td, j = idx - c * td;
-  // labels are read as the LOW dwords of the int64 copy (4-byte loads; values < num_classes): the one
-  // unexplained miscompute of this path involved 8-byte loads on this stream
-  const int* __restrict__ y32 = reinterpret_cast<const int*>(y);
+  const bool live = idx < ncls * td;
+  const int c = live ? idx / td : 0, j = live ? idx - c * td : 0;
+  // labels are read as the LOW dwords of the int64 copy (values < num_classes), 256 at a time into LDS, by
+  // agent-scope loads: served by the coherent point, whatever line of that address this XCD's L2 may hold (the one
+  // unexplained miscompute of this path was one stale-looking 128-byte line of such a copy)
+  const int* y32 = reinterpret_cast<const int*>(y);
   float s = 0.f;
-  for (int n = 0; n < B; ++n)
-    if (y32[2 * n] == c) s += g_emb[(size_t)n * td + j];
-  de[idx] = s;
+  for (int n0 = 0; n0 < B; n0 += 256) {
+    __syncthreads();
+    if (n0 + (int)threadIdx.x < B)
+      ys[threadIdx.x] = __hip_atomic_load(y32 + 2 * (n0 + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int nn = min(256, B - n0);
+    if (live)
+      for (int n = 0; n < nn; ++n)
+        if (ys[n] == c) s += g_emb[(size_t)(n0 + n) * td + j];
+  }
+  if (live) de[idx] = s;
 }
 
 // the text embeddings of kind 1 come from a frozen encoder (conditional_diffusion_laion.py:216-218):
@@ -487,6 +528,8 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
                                                         g_tdx_diag_buffer);
   else if (g_tdx_time_l1_impl == 1 && t_i64 && td == TD)
     time_l1_bwd_i64_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
+  else if (g_tdx_time_l1_impl == 3 && t_i64 && td == TD)
+    time_l1_bwd_i64_coherent_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   else
     time_l1_bwd_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, td);
   TDX_CHECK_LAUNCH();
