@@ -1,0 +1,177 @@
+"""Parity at every size bench.py reports a number for (B = 256 per GPU), beyond the fp32 MNIST headline
+that tests/test_gpu_unet.py::test_benchmarked_batch_256_against_oracle covers:
+
+  * MNIST UNet, bf16 compute mode                       (bench.py `bf16_mode`)
+  * LAION UNet fp32 at (4,32,32) and (4,64,64)          (`laion_unet.train_B256`, `train_B256_hw64`)
+  * LAION UNet bf16 at (4,32,32) and (4,64,64)          (`laion_unet.bf16.*`)
+
+The launch geometry at these sizes (tile templates, weight-gradient split plans - the bf16 mode has a split
+plan of its own) is asserted through tdx_conv3x3_tile_shape / tdx_conv3x3_wgrad_splits[_bf16], so the
+tests stay worth their CPU time if the planners change.  Reference: conditional_diffusion_laion.py:304-332
+(forward), 460-471 (step); diffusion.py:109-162, 225-236.
+
+Tolerances: fp32 - eps_hat relative MSE <= 1e-9 against the CPU oracle and every gradient within 10x of
+the fp32 oracle's own distance from an fp64 evaluation (floor 1e-4), with the GPU's max-pool routing
+(checked to differ from the exact one only at ties < 1e-4).  bf16 - eps_hat MSE <= 5e-4,
+loss within 2 %, gradient cosine >= 0.95 worst / >= 0.99 median against the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle import ref_laion as RL  # noqa: E402
+from oracle.weights import make_state_dict, make_state_dict_laion  # noqa: E402
+from parity_helpers import gpu_pool_routing, grad_precision_failures, is_pre_bn_bias, rel_mse  # noqa: E402
+
+B = 256
+REL_MSE_TOL = 1e-9
+BF16_EPS_MSE_TOL = 5e-4
+_cache = {}
+
+
+def _lib():
+    from tiny_diffusion_amd._lib import lib
+    return lib
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1).cpu()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-300)).item()
+
+
+def _bf16_gate(m, args_gpu, noise, eps_ref, loss_ref, grads_ref, tag):
+    eps = m(*args_gpu)
+    loss = F.mse_loss(eps, noise.cuda())
+    loss.backward()
+    mse = ((eps.detach().cpu().double() - eps_ref.double()) ** 2).mean().item()
+    print(f"{tag}: bf16 eps_hat MSE vs the fp32 oracle {mse:.3e}, loss {loss.item():.5f} vs {loss_ref:.5f}")
+    assert mse <= BF16_EPS_MSE_TOL, (tag, mse)
+    assert abs(loss.item() - loss_ref) <= 2e-2 * abs(loss_ref), (tag, loss.item(), loss_ref)
+    cos = []
+    for k, p in m.named_parameters():
+        if is_pre_bn_bias(k):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        cos.append((_cos(p.grad, grads_ref[k]), k))
+    cos.sort()
+    med = cos[len(cos) // 2][0]
+    print(f"{tag}: gradient cosine vs the fp32 oracle: worst {cos[:3]}, median {med:.5f}")
+    assert cos[0][0] >= 0.95 and med >= 0.99, (cos[:3], med)
+
+
+# ------------------------------------------------------------------------------------- MNIST, bf16
+def test_mnist_bf16_at_bench_batch():
+    from tiny_diffusion_amd.diffusion import NoiseModel
+
+    lib = _lib()
+    # the bf16 mode's own split plan at B = 256: 128x128 tiles (twice the slabs) on the deep layers
+    assert lib.tdx_conv3x3_wgrad_splits_bf16(B, 7, 7, 512, 512) == 8
+    assert lib.tdx_conv3x3_wgrad_splits_bf16(B, 8, 8, 1024, 256) == 8
+    assert lib.tdx_conv3x3_wgrad_splits_bf16(B, 28, 28, 64, 128) == 224
+    sd = make_state_dict(11, False)
+    g = torch.Generator().manual_seed(2560)
+    x0 = torch.rand(B, 1, 28, 28, generator=g) * 2 - 1
+    noise = torch.randn(B, 1, 28, 28, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    x_t = R.q_sample(R.Schedule(), x0, t, noise)
+    loss_ref, eps_ref, g32, _ = R.train_step_grads(sd, x_t, t, noise, None)
+    m = NoiseModel(); m.load_state_dict(sd); m = m.cuda().train().set_compute_dtype(torch.bfloat16)
+    _bf16_gate(m, (x_t.cuda(), t.cuda()), noise, eps_ref, loss_ref.item(), g32, "mnist bf16 B=256")
+
+
+# ------------------------------------------------------------------------------------------- LAION
+def _laion_inputs(hw):
+    g = torch.Generator().manual_seed(1000 + hw)
+    x = torch.randn(B, 4, hw, hw, generator=g) * 0.8
+    noise = torch.randn(B, 4, hw, hw, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cond = torch.randn(B, 768, generator=g)
+    return x, noise, t, cond
+
+
+def _laion_model(sd):
+    from tiny_diffusion_amd.conditional_diffusion_laion import NoiseModel
+
+    m = NoiseModel(time_dim=768)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train()
+
+
+def _laion_pool_routing(m, hw, sd, x, t, cond):
+    """The GPU forward's arg-max per pooling window, checked against the exact (fp64) routing at ties only."""
+    plan = [p for key, p in m._plans.items() if key[1] == B and (key[2] if len(key) > 2 else 32) == hw][0]
+    taps = {}
+    p64, b64 = R.split_state(sd)
+    p64 = {k: v.double() for k, v in p64.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in b64.items()}
+    with torch.no_grad():
+        RL.unet_forward(p64, b64, x.double(), t, cond.double(), training=True, taps=taps)
+    out = {}
+    for name, unit, H, Cc in (("e1", 1, hw, 64), ("e2", 3, hw // 2, 128), ("e3", 5, hw // 4, 256)):
+        Y = plan.tensor(f"Y{unit}").view(B, H, H, Cc)
+        ss = plan.tensor(f"ss{unit}")
+        a = torch.relu(torch.addcmul(ss[Cc:2 * Cc], Y, ss[:Cc])).permute(0, 3, 1, 2).cpu()
+        idx = R.pool_windows(a).argmax(dim=-1, keepdim=True)
+        w64 = R.pool_windows(taps[name])
+        differ = (idx != w64.argmax(dim=-1, keepdim=True)).squeeze(-1)
+        if differ.any():
+            rms = taps[name].pow(2).mean().sqrt().item()
+            picked = torch.gather(w64, -1, idx)[differ].squeeze(-1)
+            best = w64[differ].max(dim=-1).values
+            gap = (best - picked) / torch.maximum(best.abs(), torch.tensor(rms, dtype=best.dtype))
+            assert gap.max().item() < 1e-4, (name, int(differ.sum()), gap.max().item())
+        out[name] = idx
+    return out
+
+
+def _laion_geometry(hw):
+    lib = _lib()
+    s = hw // 32
+    # forward / input-gradient tiles and the fp32 / bf16 pixel splits of the thin top level and a deep level
+    assert lib.tdx_conv3x3_tile_shape(B, 32 * s, 32 * s, 64, 64, 0) == 128064
+    assert lib.tdx_conv3x3_tile_shape(B, 16 * s, 16 * s, 128, 128, 0) == 128128
+    assert lib.tdx_conv3x3_tile_shape(B, 8 * s, 8 * s, 512, 256, 0) == 128128
+    assert lib.tdx_conv3x3_wgrad_splits(B, 32 * s, 32 * s, 64, 64) == (222 if hw == 32 else 226)
+    assert lib.tdx_conv3x3_wgrad_splits(B, 8 * s, 8 * s, 512, 256) == (8 if hw == 32 else 14)
+    assert lib.tdx_conv3x3_wgrad_splits_bf16(B, 32 * s, 32 * s, 64, 64) == 228
+    assert lib.tdx_conv3x3_wgrad_splits_bf16(B, 8 * s, 8 * s, 512, 256) == 15
+
+
+@pytest.mark.parametrize("hw", [32, 64])
+def test_laion_fp32_at_bench_batch(hw):
+    _laion_geometry(hw)
+    sd = make_state_dict_laion(6)
+    x, noise, t, cond = _laion_inputs(hw)
+    m = _laion_model(sd)
+    eps = m(x.cuda(), t.cuda(), cond.cuda())
+    loss = F.mse_loss(eps, noise.cuda())
+    loss.backward()
+    pidx = _laion_pool_routing(m, hw, sd, x, t, cond)
+    loss_ref, eps_ref, g32, bufs = RL.train_step_grads(sd, x, t, noise, cond, pool_idx=pidx)
+    _cache[hw] = (loss_ref.item(), eps_ref, g32)
+    _, _, g64, _ = RL.train_step_grads(sd, x, t, noise, cond, dtype=torch.float64, pool_idx=pidx)
+    r = rel_mse(eps.detach(), eps_ref)
+    print(f"laion fp32 B=256 {hw}x{hw}: eps_hat rel MSE {r:.3e}")
+    assert r < REL_MSE_TOL
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * loss_ref.item()
+    bad = grad_precision_failures({k: p.grad for k, p in m.named_parameters()}, g32, g64, True)
+    assert not bad, bad
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert torch.allclose(v.cpu(), bufs[k], rtol=2e-5, atol=2e-5), k
+
+
+@pytest.mark.parametrize("hw", [32, 64])
+def test_laion_bf16_at_bench_batch(hw):
+    _laion_geometry(hw)
+    sd = make_state_dict_laion(6)
+    x, noise, t, cond = _laion_inputs(hw)
+    if hw not in _cache:   # (run alone: the fp32 test of the same size leaves the oracle's results behind)
+        loss_ref, eps_ref, g32, _ = RL.train_step_grads(sd, x, t, noise, cond)
+        _cache[hw] = (loss_ref.item(), eps_ref, g32)
+    loss_ref, eps_ref, g32 = _cache.pop(hw)
+    m = _laion_model(sd).set_compute_dtype(torch.bfloat16)
+    _bf16_gate(m, (x.cuda(), t.cuda(), cond.cuda()), noise, eps_ref, loss_ref, g32, f"laion bf16 B=256 {hw}x{hw}")

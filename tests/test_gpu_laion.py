@@ -296,6 +296,48 @@ def test_laion_train_step_adam():
             assert diff.max().item() <= 2.1e-4, k
             assert (diff > 1e-6).float().mean().item() <= 2e-3, (k, (diff > 1e-6).float().mean().item())
 
+        # The first step alone cannot see the clip coefficient (lr*c*g / (c*|g| + eps): a uniform scale c
+        # cancels).  The MOMENTS can, and so can the next steps: two more steps on fresh data, comparing
+        # exp_avg / exp_avg_sq (views of TrainStep's flat buffers) with torch.optim.Adam's state after
+        # clip_grad_norm_ on the reference side.  A coefficient off by 2x would be a 2x / 4x error here.
+        def check_moments(step):
+            for k, p in ref.named_parameters():
+                if is_pre_bn_bias(k):
+                    continue   # exactly-zero gradients on one side, rounding noise on the other
+                lo, hi = ts.offsets[k]
+                st = opt.state[p]
+                for name, flat in (("exp_avg", ts.exp_avg), ("exp_avg_sq", ts.exp_avg_sq)):
+                    got, want = flat[lo:hi].double().cpu(), st[name].reshape(-1).double().cpu()
+                    err = (got - want).norm().item() / max(want.norm().item(), 1e-30)
+                    # the two replicas drift apart by ulps after step 1 and train-mode BatchNorm at B = 4
+                    # amplifies that (measured worst: 2.2e-3 on a BatchNorm bias in step 3)
+                    assert err < 2e-2, (max_norm, step, k, name, err)
+
+        check_moments(1)
+        for step in (2, 3):
+            x0 = torch.randn(4, 4, 32, 32, generator=g).cuda()
+            noise = torch.randn(4, 4, 32, 32, generator=g).cuda()
+            t = torch.randint(0, 1000, (4,), generator=g).cuda()
+            cond = torch.randn(4, 768, generator=g).cuda()
+            loss = ts.step(x0, cond, t=t, noise=noise)
+            x_t, _ = fp.q_sample("cuda", x0, t, noise=noise)
+            l2 = F.mse_loss(ref(x_t, t, cond), noise)
+            opt.zero_grad()
+            l2.backward()
+            total = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=max_norm)
+            if max_norm < 100.0:
+                assert total.item() > max_norm   # the clip is active in every step of the 10.0 case
+            opt.step()
+            assert abs(float(loss) - l2.item()) <= 1e-3 * abs(l2.item()), (step, float(loss), l2.item())
+            check_moments(step)
+        assert ts.step_count == 3
+        for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+            if is_pre_bn_bias(k):
+                continue
+            # three steps of at most lr = 1e-4 each; the replicas saw gradients that agree to ~1e-3
+            assert (a - b).abs().max().item() <= 3.2e-4, k
+            assert (a - b).abs().mean().item() <= 2e-6, (k, (a - b).abs().mean().item())
+
 
 def test_train_step_graph_replay_matches_eager():
     """TrainStep(use_graph=True): the whole step captured in one HIP graph (torch's graph-safe

@@ -484,6 +484,84 @@ def test_mse_and_adam(tdx):
     assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("gscale", [1.0, 0.25])
+@pytest.mark.parametrize("hyper_form", [False, True])
+@pytest.mark.parametrize("gnorm,max_norm", [(37.5, 10.0), (3.0, 10.0), (10.0, 10.0)])
+def test_adam_step_clip_three_steps(tdx, gnorm, max_norm, hyper_form, gscale):
+    """tdx_adam_step_clip = torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()
+    (conditional_diffusion_laion.py:469-472) on the flat gradient, over THREE steps with gradients of a
+    known norm (clip active: 37.5 > 10; inactive: 3 < 10; on the edge: 10, where torch's
+    max_norm / (norm + 1e-6) < 1 still scales), comparing exp_avg, exp_avg_sq and the parameters.  One step
+    from zero moments would not do: Adam's first update lr*g/(|g|+eps) is invariant to a uniform scale of
+    g, so a wrong clip coefficient would pass (the moments and the later steps are not invariant).
+    `gscale` is the 1/world of the data-parallel mean: the reference then clips the AVERAGED gradient.
+    `hyper_form`: step scalars read from device memory (the graph-capturable form)."""
+    import math
+
+    n = 70001   # not a multiple of the block size
+    g = torch.Generator().manual_seed(int(gnorm * 10) + int(hyper_form))
+    p0 = torch.randn(n, generator=g)
+    # several "parameters" on the torch side (the norm is taken over all of them together)
+    cuts = [0, 1000, 1001, 40000, n]
+    ref = [p0[a:b].clone().requires_grad_(True) for a, b in zip(cuts[:-1], cuts[1:])]
+    lr, b1, b2, eps = 1e-4, 0.9, 0.999, 1e-8
+    opt = torch.optim.Adam(ref, lr=lr, betas=(b1, b2), eps=eps)
+    pd = dev(p0.clone())
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    scratch = torch.empty(tdx.lib.tdx_adam_clip_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    hyper = torch.zeros(3, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        # the averaged gradient has norm gnorm * (1, 1.7, 0.4): the 3-norm case is clipped in step 2 only...
+        gr = gr * (gnorm * (1.0, 1.7, 0.4)[step - 1] / gr.norm()) / gscale
+        for r, a, b in zip(ref, cuts[:-1], cuts[1:]):
+            r.grad = (gr[a:b] * gscale).clone()
+        total = torch.nn.utils.clip_grad_norm_(ref, max_norm=max_norm)
+        assert abs(total.item() - gnorm * (1.0, 1.7, 0.4)[step - 1]) < 1e-3 * gnorm
+        opt.step()
+        if hyper_form:
+            bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+            hyper.copy_(torch.tensor([lr / bc1, 1.0 / math.sqrt(bc2), gscale], dtype=torch.float32))
+            torch.cuda.synchronize()
+        tdx.check(tdx.lib.tdx_adam_step_clip(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, b1,
+                                             b2, eps, step, gscale, max_norm, hyper.data_ptr() if hyper_form else None,
+                                             scratch.data_ptr(), stream()))
+        st = [opt.state[r] for r in ref]
+        m_ref = torch.cat([s["exp_avg"] for s in st])
+        v_ref = torch.cat([s["exp_avg_sq"] for s in st])
+        p_ref = torch.cat([r.detach() for r in ref])
+        # moments: a coefficient off by 2x would show as a 2x / 4x error.  The bound is the rounding of the
+        # NORM: torch sums the squares in fp32 (measured: its coefficient is 6e-6 off the double-precision
+        # one over 70 k elements), the kernel in double
+        assert rel_err(m, m_ref) < 3e-5, (step, rel_err(m, m_ref))
+        assert rel_err(v, v_ref) < 6e-5, (step, rel_err(v, v_ref))
+        assert (pd.cpu() - p_ref).abs().max().item() < 2e-6, step
+
+
+def test_adam_step_clip_detects_wrong_coefficient(tdx):
+    """Sensitivity of the gate above: the same three steps against a torch run whose clip threshold is
+    DOUBLED must fail the moment comparison by a wide margin (so a kernel with a wrong coefficient cannot
+    pass test_adam_step_clip_three_steps)."""
+    n = 5000
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = [p0.clone().requires_grad_(True)]
+    opt = torch.optim.Adam(ref, lr=1e-4)
+    pd = dev(p0.clone())
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    scratch = torch.empty(tdx.lib.tdx_adam_clip_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        gr = gr * (40.0 / gr.norm())
+        ref[0].grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, max_norm=20.0)   # the kernel is given 10.0
+        opt.step()
+        tdx.check(tdx.lib.tdx_adam_step_clip(pd.data_ptr(), dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4,
+                                             0.9, 0.999, 1e-8, step, 1.0, 10.0, None, scratch.data_ptr(), stream()))
+    s = opt.state[ref[0]]
+    assert rel_err(m, s["exp_avg"]) > 0.3 and rel_err(v, s["exp_avg_sq"]) > 0.5
+
+
 def test_u8_gather_normalize_bit_exact(tdx):
     """ToTensor + Normalize((0.5,),(0.5,)) (diffusion.py:202-204) fused with the gather."""
     from tiny_diffusion_amd.data import DeviceImageDataset

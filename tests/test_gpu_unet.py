@@ -561,3 +561,30 @@ def test_time_dim_constructor_argument(time_dim):
     for bad_dim in (100, 384, 2048):
         with pytest.raises(ValueError):
             NoiseModel(time_dim=bad_dim)
+
+
+def test_train_step_graph_capture_three_streams():
+    """TrainStep(use_graph=True) on the MNIST network with its default THREE-stream schedule: the captured
+    step (helper streams forked inside the capture; the slab reductions move onto the weight-gradient
+    stream for the capture - csrc/unet.hip, tools/micro/capture_fork_probe.hip) replays to the same
+    parameters as the eager step with the same seeds.  Round 2 forced captured steps onto one stream
+    because hipStreamEndCapture crashed; this is the regression test for the real cause."""
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+    from tiny_diffusion_amd.train import TrainStep
+
+    fp = ForwardProcess()
+    g = torch.Generator().manual_seed(21)
+    xs = [(torch.rand(16, 1, 28, 28, generator=g) * 2 - 1).cuda() for _ in range(4)]
+    out = []
+    for use_graph in (False, True):
+        m = build(False, 5).train()
+        assert m._stream_mode == -1
+        ts = TrainStep(m, fp, lr=1e-3, use_graph=use_graph)
+        assert m._stream_mode == -1          # the schedule is not overridden for the capture any more
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        losses = [float(ts.step(x)) for x in xs]
+        assert (ts._graph is not None) == use_graph
+        out.append((losses, ts.flat_param.clone()))
+    (l0, p0), (l1, p1) = out
+    assert np.allclose(l0, l1, rtol=1e-5), (l0, l1)
+    assert (p0 - p1).abs().max().item() <= 2e-5

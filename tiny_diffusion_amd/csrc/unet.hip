@@ -760,6 +760,21 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   float* g_next = u->g_next;
 
   tdx_stream_t side = reinterpret_cast<tdx_stream_t>(u->side);
+  // Stream capture (TrainStep(use_graph=True)).  The eager schedule makes the two helper streams wait for
+  // EACH OTHER (slab reduction on the third stream behind the weight-gradient GEMM of the second; the GEMM
+  // two units later behind that reduction, whose slab buffer it overwrites) while both are also forked from
+  // the caller's stream.  That is legal under the rules of capture - every event waited for is recorded
+  // inside the capture, both helpers are joined before EndCapture - but hipStreamEndCapture of ROCm 7.2
+  // dies on it with a segmentation fault.  tools/micro/capture_fork_probe.hip reproduces it without libtdx
+  // (case 12: this function's event sequence with one-line kernels) and bisects it: any ONE of the two
+  // cross-helper waits removed, or the third stream's forks from the caller's stream removed, and the
+  // capture ends and replays correctly; origin <-> helper forks and joins alone are fine in every
+  // combination tried (cases 0-11).  So inside a capture the reduction runs on the GEMM's own stream:
+  // no helper ever waits for the other, everything else (three streams, the same kernels, the same
+  // summation orders, bit-identical results) stays.
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap_status);
+  const bool capturing = cap_status == hipStreamCaptureStatusActive;
   // unit_bwd: g_next holds dL/d(activation of unit i); afterwards that buffer holds
   // dL/d(conv output) (read by the wgrad on the side stream) and *g_in_out the input gradient
   auto unit_bwd = [&](int i, const float* in, float** g_in_out) -> int {
@@ -782,6 +797,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     // The split-K slabs alternate between two buffers; the (HBM-bound) slab reduction runs on the
     // third stream.  Unit i's slab buffer was last read by the reduction of unit i+2.
     hipStream_t wst = fork ? u->side : st;
+    hipStream_t red_st = capturing ? wst : u->side2;
     if (fork) {
       TDX_HIP(hipEventRecord(u->ev_dy[i], st));
       TDX_HIP(hipStreamWaitEvent(u->side, u->ev_dy[i], 0));
@@ -798,13 +814,17 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                            reinterpret_cast<tdx_stream_t>(wst)));
     // dy is free again once the wgrad GEMM has read it
     TDX_HIP(hipEventRecord(u->ev_w[i], wst));
-    TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_w[i], 0));
+    // the slab reduction: third stream - or, while the step is being CAPTURED, right behind the GEMM on its
+    // own stream (red_st, see the top of this function), which needs neither of the two cross-helper waits
+    if (red_st != wst) TDX_HIP(hipStreamWaitEvent(red_st, u->ev_w[i], 0));
     RC(tdx_conv3x3_wgrad_reduce_pad(slab, G[TDX_P_UNIT0 + 4 * i],
                                     bf16 ? tdx_conv3x3_wgrad_splits_bf16(B, d.hw, d.hw, d.cin, d.cout)
                                          : tdx_conv3x3_wgrad_splits(B, d.hw, d.hw, d.cin, d.cout),
-                                    d.cout, d.cin, d.cin_real, reinterpret_cast<tdx_stream_t>(u->side2)));
-    TDX_HIP(hipEventRecord(u->ev_red[i], u->side2));
-    u->red_pending[i] = true;
+                                    d.cout, d.cin, d.cin_real, reinterpret_cast<tdx_stream_t>(red_st)));
+    if (red_st != wst) {
+      TDX_HIP(hipEventRecord(u->ev_red[i], red_st));
+      u->red_pending[i] = true;
+    }
     GBuf* gbuf = find(g);
     gbuf->w_unit = i;
     gbuf->age = ++clock;

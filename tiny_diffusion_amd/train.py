@@ -153,11 +153,9 @@ class TrainStep:
         # are bound by the GPU-side cost of ~100-170 tiny dependent kernels, not by host launches
         # (LAION B=8: 2.18 -> 2.05 ms/step; latent MLP B=128: 0.62 -> 0.68), so it is off by default.
         self.use_graph = use_graph
-        if use_graph:
-            # a captured step runs on ONE stream: ending a capture that forked into the library's helper
-            # streams crashed inside the HIP runtime (ROCm 7.2); small-batch steps, which are what graphs
-            # are for, gain nothing from the overlap anyway
-            model._stream_mode = 0
+        # (a captured step keeps the model's stream schedule: libtdx notices the capture and avoids the one
+        # cross-helper-stream wait pattern that crashes hipStreamEndCapture on ROCm 7.2 - csrc/unet.hip,
+        # tools/micro/capture_fork_probe.hip)
         self._graph = None
         self._graph_key = None
         self._hyper = None
