@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TDX_VERSION 210 /* 0.2.1: additions only since 0.2.0 (boundary convolutions, tdx_conv3x3_fwd_train, bf16 split plan, stream schedule); tdx_time_mlp_bwd scratch grew in 0.2.0 */
+#define TDX_VERSION 300 /* 0.3.0: tdx_diag_set_buffer takes the buffer size (incompatible); additions: tdx_timestep_embedding_f32, tdx_initial_conv_input_grad, tdx_unet_request_input_grad; time_dim of any width */
 
 #define TDX_E_BADARG (-1)   /* null pointer, size <= 0, batch > plan capacity ... */
 #define TDX_E_SHAPE (-2)    /* shape the kernel family does not cover */
@@ -150,6 +150,11 @@ int tdx_initial_conv_forward(const float* x, const float* w, const float* bias, 
                              int cin, int cout, tdx_stream_t stream);
 int tdx_initial_conv_backward(const float* x, const float* g_out, float* dw, float* db, float* scratch, int B,
                               int H, int W, int cin, int cout, tdx_stream_t stream);
+/* d loss / d x: the input gradient of initial_conv (NCHW (B,cin,H,W)) from the gradient of its output
+ * (channels-last, 64 stored channels).  The reference's module is differentiable in x like any nn.Module
+ * (diffusion.py:116); train() and sample() never ask for it. */
+int tdx_initial_conv_input_grad(const float* g_out, const float* w, float* g_x, int B, int H, int W, int cin,
+                                int cout, tdx_stream_t stream);
 int tdx_final_conv_forward(const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
                            int cout, tdx_stream_t stream);
 int tdx_final_conv_backward(const float* in, const float* g_out, const float* w, float* g_in, float* dw, float* db,
@@ -443,10 +448,17 @@ int tdx_unet_backward(tdx_unet* u, const void* const* params, void* const* grads
  * after its own compute stream as well.) */
 int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream);
 
+/* d loss / d x on request: the NEXT tdx_unet_backward call that runs the last stage also writes the gradient
+ * w.r.t. the network input x into g_x ((B, in_ch, H, W) fp32, the shape of x), on `stream`.  One-shot: the
+ * request is cleared by that call (and by NULL).  The UNets only (the latent MLP: TDX_E_SHAPE). */
+int tdx_unet_request_input_grad(tdx_unet* u, float* g_x);
+
 /* get_timestep_embedding(timesteps, embedding_dim), conditional_diffusion_laion.py:222-232:
  * out[n][j] = sin(t_n f_j) for j < dim/2, cos(t_n f_{j-dim/2}) after, f_j = exp(-ln(1e4) j/(dim/2-1)),
  * one trailing zero column when dim is odd.  out (B, dim) fp32. */
 int tdx_timestep_embedding(const int64_t* t, float* out, int B, int dim, tdx_stream_t stream);
+/* floating-point timesteps (the reference converts with .float(): a fractional t keeps its fraction) */
+int tdx_timestep_embedding_f32(const float* t, float* out, int B, int dim, tdx_stream_t stream);
 
 /* The time / class path on its own (diffusion.py:21-25, 105-113, 130-132;
  * conditional_diffusion.py:31, 121-125): emb = W2 silu(W1 float(t) + b1) + b2 [+ E[y]], then the
@@ -488,9 +500,10 @@ int tdx_unet_pack(tdx_unet* u, const void* const* params, void* const* buffers,
  * (one / two register stages); "splitk" 0 | 1. */
 int tdx_tune_set(const char* key, int value);
 
-/* Diagnostics (tools/gpu_stage6_diag.py): device buffer that the instrumented variant of the time-path
- * kernel (knob "time_l1_impl" = 2) records its loads into; NULL disables it. */
-int tdx_diag_set_buffer(void* device_buffer);
+/* Diagnostics (tools/gpu_stage6_diag.py, gpu_clock_probe.py, ...): device buffer of `bytes` bytes that the
+ * instrumented kernels (knobs "time_l1_impl" = 2, "conv_stamp", "probe_stamp") record into; NULL disables it.
+ * A path whose records would not fit in `bytes` does not stamp (never writes past the end). */
+int tdx_diag_set_buffer(void* device_buffer, size_t bytes);
 int tdx_diag_conv_occupancy(int tile);  /* resident workgroups per CU of the forward kernel of tile bm*1000+bn */
 
 /* Peak probes used by bench.py for measured roofline denominators. */

@@ -56,7 +56,7 @@ def stream():
 
 
 def test_library_exports(tdx):
-    assert tdx.lib.tdx_version() == 210
+    assert tdx.lib.tdx_version() == 300
     maps = open("/proc/self/maps").read()
     assert "libtdx.so" in maps
 
@@ -717,3 +717,20 @@ def test_final_conv_fwd_bwd(tdx, B, H, cout):
                                               cout, stream()))
     assert rel_err(nchw(gin), x.grad) < 3e-6
     assert rel_err(dw, w.grad) < 3e-6 and rel_err(db, b.grad) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,cin,cout", [(3, 28, 1, 64), (2, 32, 4, 32), (1, 7, 1, 64), (2, 40, 4, 32)])
+def test_initial_conv_input_grad(tdx, B, H, cin, cout):
+    """tdx_initial_conv_input_grad = d/dx of nn.Conv2d(cin, cout, 3, padding=1) (diffusion.py:28, 116) given the
+    gradient of its (channels-last, 64 stored channels) output."""
+    g = torch.Generator().manual_seed(B * H + cin)
+    x = torch.randn(B, cin, H, H, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.3
+    go = torch.randn(B, cout, H, H, generator=g)
+    F.conv2d(x, w, None, padding=1).backward(go)
+    gfat = torch.full((B, H, H, 64), 7.0)          # padding channels hold junk: they must not leak in
+    gfat[..., :cout] = nhwc(go)
+    gx = torch.full((B, cin, H, H), float("nan"), device="cuda")
+    tdx.check(tdx.lib.tdx_initial_conv_input_grad(dev(gfat).data_ptr(), dev(w).data_ptr(), gx.data_ptr(), B, H, H, cin,
+                                                  cout, stream()))
+    assert rel_err(gx, x.grad) < 2e-6

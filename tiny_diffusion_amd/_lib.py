@@ -144,9 +144,12 @@ _SIGS = {
     "tdx_unet_backward": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                     _ptr]),
     "tdx_unet_backward_join": (C.c_int, [_ptr, _ptr]),
+    "tdx_unet_request_input_grad": (C.c_int, [_ptr, _ptr]),
+    "tdx_initial_conv_input_grad": (C.c_int, [_ptr, _ptr, _ptr] + [C.c_int] * 5 + [_ptr]),
     "tdx_unet_eval_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
                                      _ptr, C.c_size_t, C.c_int, C.c_uint64, _ptr]),
     "tdx_timestep_embedding": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, _ptr]),
+    "tdx_timestep_embedding_f32": (C.c_int, [_ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_time_mlp_fwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr]),
     "tdx_time_mlp_bwd": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int, C.c_int,
                                    _ptr]),
@@ -155,7 +158,7 @@ _SIGS = {
     "tdx_unet_pack": (C.c_int, [_ptr, _ptr, _ptr, _ptr]),
     "tdx_unet_tensor": (C.c_int, [_ptr, C.c_int, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "tdx_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
-    "tdx_diag_set_buffer": (C.c_int, [_ptr]),
+    "tdx_diag_set_buffer": (C.c_int, [_ptr, C.c_size_t]),
     "tdx_probe_mfma_f32": (C.c_int, [_ptr, C.c_int, C.c_int, _ptr]),
     "tdx_probe_stream_copy": (C.c_int, [_ptr, _ptr, C.c_int64, _ptr]),
 }

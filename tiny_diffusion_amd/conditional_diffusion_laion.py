@@ -22,15 +22,20 @@ TIME_DIM = ARCH_LAION.time_dim
 
 def get_timestep_embedding(timesteps, embedding_dim):
     """conditional_diffusion_laion.py:222-232 on the device: ``tdx_timestep_embedding`` (the kernel
-    the model's own time path runs).  (N,) integer timesteps -> (N, embedding_dim) fp32."""
+    the model's own time path runs).  (N,) timesteps -> (N, embedding_dim) fp32.  Integer timesteps go
+    through the int64 kernel; floating-point ones (the reference takes ``timesteps[:, None].float()``, so a
+    fractional t keeps its fraction) through ``tdx_timestep_embedding_f32``.  A CPU tensor raises: this
+    package has no host path."""
     if not timesteps.is_cuda:
         raise _lib.TdxError("get_timestep_embedding runs on the GPU only (no CPU fallback)")
-    t = timesteps.contiguous().to(torch.int64)
+    if timesteps.is_floating_point():
+        t, fn, name = timesteps.contiguous().to(torch.float32), _lib.lib.tdx_timestep_embedding_f32, "tdx_timestep_embedding_f32"
+    else:
+        t, fn, name = timesteps.contiguous().to(torch.int64), _lib.lib.tdx_timestep_embedding, "tdx_timestep_embedding"
     out = torch.empty((t.shape[0], int(embedding_dim)), dtype=torch.float32, device=t.device)
     if t.shape[0]:
-        _lib.check(_lib.lib.tdx_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], int(embedding_dim),
-                                                   torch.cuda.current_stream(t.device).cuda_stream),
-                   "tdx_timestep_embedding")
+        _lib.check(fn(t.data_ptr(), out.data_ptr(), t.shape[0], int(embedding_dim),
+                      torch.cuda.current_stream(t.device).cuda_stream), name)
     return out
 
 

@@ -672,6 +672,7 @@ static int g_conv_impl = 0;           // main-loop variant of the non-split laun
 static int g_conv_dbg = 0;
 static int g_conv_stamp = 0;           // diagnostics: LDS-DMA forward kernels stamp their main loop into the diag buffer
 extern unsigned* g_tdx_diag_buffer;    // time_embed.hip (tdx_diag_set_buffer)
+extern size_t g_tdx_diag_bytes;
 extern int g_tdx_probe_stamp;
 static int g_conv_dma = 1;             // raw-input convolutions fetch their tiles by LDS-DMA (variant 3)
 static int g_splitk = 1;              // 0: never split K; 1: split K when the grid would not fill the chip
@@ -1077,8 +1078,12 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   // slot counter: the tool resets it with conv_stamp = 0)
   static int slot = 0;
   if (g_conv_stamp == 0) slot = 0;
-  a.stamps = stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr;
-  if (g_conv_stamp == 2 && stats_partial && g_tdx_diag_buffer && slot < 16)
+  // a workgroup writes one 64-byte record at index blockIdx.x; no launch has more workgroups than 64x64 tiles
+  const size_t max_wgs = (size_t)cdiv(a.M, 64) * (size_t)(cout / 64), rec = 8 * sizeof(unsigned long long);
+  a.stamps = stamp && g_tdx_diag_buffer && max_wgs * rec <= g_tdx_diag_bytes
+                 ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr;
+  if (g_conv_stamp == 2 && stats_partial && g_tdx_diag_buffer && slot < 16 && max_wgs <= 8192 &&
+      (size_t)(slot + 1) * 8192 * rec <= g_tdx_diag_bytes)
     a.stamps = reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) + (size_t)(slot++) * 8 * 8192;
   hipStream_t st = to_stream(stream);
   if (train && splitk_scratch && !(flags & (TDX_CONV_IN_BNRELU | TDX_CONV_OUT_BNRELU)) && g_conv_dma) {

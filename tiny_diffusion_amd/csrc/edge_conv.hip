@@ -115,14 +115,25 @@ thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict_
 // float4 per lane - was tried: 210 VGPRs, two waves per SIMD, 152 us instead of 54 at CO = 4.  What is
 // left on the table is the LDS weight traffic, one b128 read per four FMAs; the GEMM form
 // Z[q][(o,tap)] = in[q][:] . W[o][:][tap] followed by a 9-neighbour gather would read `in` once.)
-template <int CO>
+// DGRAD = true: the input gradient of initial_conv with the same loop.  g_x[n][c][p] =
+// sum_{o,tap} g(x0)[p - tap][o] W[o][c][tap] = sum_{tap'} sum_o g(x0)[p + tap'][o] W[o][c][8 - tap'], i.e. this
+// kernel on the gradient of x0 with the weight image ws[c][tap'][o] = initial_conv.weight[o][c][8 - tap'] (w is
+// [cor][CO][9]; stored channels o >= cor are padding: zero weights) and no bias.
+template <int CO, bool DGRAD = false>
 __global__ void __launch_bounds__(256)
 fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int cor = IC_CO) {
   __shared__ __attribute__((aligned(16))) float ws[CO][9][IC_CO];
-  for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {  // w is [co][ci][tap]
-    const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
-    ws[co][r % 9][r / 9] = w[i];
+  if (DGRAD) {
+    for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {
+      const int c = i / (9 * IC_CO), r = i % (9 * IC_CO), tap = r / IC_CO, o = r % IC_CO;
+      ws[c][tap][o] = o < cor ? w[(o * CO + c) * 9 + (8 - tap)] : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {  // w is [co][ci][tap]
+      const int co = i / (9 * IC_CO), r = i % (9 * IC_CO);
+      ws[co][r % 9][r / 9] = w[i];
+    }
   }
   __syncthreads();
   const int ci = (threadIdx.x & 15) * 4, pl = threadIdx.x >> 4;
@@ -131,7 +142,7 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
   const int64_t Mpad = (M + 15) / 16 * 16;
   float bv[CO];
 #pragma unroll
-  for (int co = 0; co < CO; ++co) bv[co] = bias[co];
+  for (int co = 0; co < CO; ++co) bv[co] = DGRAD ? 0.f : bias[co];
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
     float s[CO];
 #pragma unroll
@@ -242,7 +253,11 @@ thin_fat_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ 
       if (kind[cb] == 1) v = qv ? 1.f : 0.f;
       else if (kind[cb] != 2) {
         const bool ok = qv && (unsigned)(oh + kdy[cb]) < (unsigned)H && (unsigned)(ow + kdx[cb]) < (unsigned)W;
-        v = ok ? tb[koff[cb]] : 0.f;
+        // initial_conv (FLIP = false): `thin` is the workspace COPY of the model input that the forward made
+        // with hipMemcpyAsync, and this kernel may run on a helper stream - the shape of the one hand-off
+        // that was seen stale from one XCD: read it at agent scope (L2-served `sc1` loads,
+        // 0.8 MB in all: free).  final_conv's thin operand is a kernel's output on the same stream: plain.
+        v = !ok ? 0.f : FLIP ? tb[koff[cb]] : __hip_atomic_load(tb + koff[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (FLIP && kind[cb] == 3) dbacc[cb] += v;
       }
       bq[cb] = v;
@@ -409,6 +424,20 @@ int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float
   return 0;
 }
 
+// d loss / d x of the network: the input gradient of initial_conv (the reference's module is differentiable in
+// its input like any nn.Module, diffusion.py:116; not needed by train() or sample(), so only on request).
+// g_x0: channels-last, 64 stored channels; g_x: NCHW (B, cin, H, W).
+int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
+                           int cout_real, hipStream_t st) {
+  const int64_t M = (int64_t)B * H * W;
+  const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
+  if (cin == 1 && cout_real == 64) fat_to_thin_conv_kernel<1, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
+  else if (cin == 4 && cout_real == 32) fat_to_thin_conv_kernel<4, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 int tdx_small_conv_wgrad_blocks(int B, int H, int W) {
   return cdiv((int64_t)B * H * W, WGRAD_PIX);
 }
@@ -454,6 +483,11 @@ extern "C" int tdx_initial_conv_backward(const float* x, const float* g_out, flo
                                          int B, int H, int W, int cin, int cout, tdx_stream_t stream) {
   if (!x || !g_out || !dw || !db || !scratch || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   return tdx_initial_conv_wgrad(x, g_out, scratch, dw, db, B, H, W, cin, cout, to_stream(stream));
+}
+extern "C" int tdx_initial_conv_input_grad(const float* g_out, const float* w, float* g_x, int B, int H, int W,
+                                           int cin, int cout, tdx_stream_t stream) {
+  if (!g_out || !w || !g_x || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  return tdx_initial_conv_dgrad(g_out, w, g_x, B, H, W, cin, cout, to_stream(stream));
 }
 extern "C" int tdx_final_conv_forward(const float* in, const float* w, const float* bias, float* out, int B, int H,
                                       int W, int cout, tdx_stream_t stream) {

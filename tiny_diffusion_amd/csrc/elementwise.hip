@@ -482,12 +482,14 @@ __global__ void __launch_bounds__(256) probe_mfma_kernel(float* out, int iters, 
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 extern unsigned* g_tdx_diag_buffer;
+extern size_t g_tdx_diag_bytes;
 extern int g_tdx_probe_stamp;
 
 extern "C" int tdx_probe_mfma_f32(float* out, int iters, int blocks, tdx_stream_t stream) {
   if (!out || iters <= 0 || blocks <= 0) return TDX_E_BADARG;
   probe_mfma_kernel<<<blocks, 256, 0, to_stream(stream)>>>(
-      out, iters, g_tdx_probe_stamp ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr);
+      out, iters, g_tdx_probe_stamp && g_tdx_diag_buffer && (size_t)blocks * 64 <= g_tdx_diag_bytes
+                       ? reinterpret_cast<unsigned long long*>(g_tdx_diag_buffer) : nullptr);
   TDX_CHECK_LAUNCH();
   return 0;
 }

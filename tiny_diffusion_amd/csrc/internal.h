@@ -14,6 +14,8 @@ int tdx_small_conv_wgrad_blocks(int B, int H, int W);
 int tdx_small_conv_partial_width(void);
 int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
                            int B, int H, int W, int cin, int cout_real, hipStream_t st);
+int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
+                           int cout_real, hipStream_t st);
 int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
                        int W, int cout, hipStream_t st);
 int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,

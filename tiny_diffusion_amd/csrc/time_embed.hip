@@ -88,7 +88,8 @@ time_proj_kernel(const float* __restrict__ emb, const float* __restrict__ pw1,
 // ------------------------------------------------------------------ kind 1
 // sinusoid[n][j] = sin(t * f_j) for j < 384, cos(t * f_{j-384}) after;
 // f_j = exp(-ln(10000) * j / 383), every operation rounded to fp32 in the reference's order
-__global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim) {
+template <typename T>
+__global__ void sinusoid_kernel(const T* __restrict__ t, float* __restrict__ out, int B, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * dim) return;
   const int n = i / dim, j = i - n * dim, half = dim / 2;
@@ -104,7 +105,17 @@ __global__ void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict
 extern "C" int tdx_timestep_embedding(const int64_t* t, float* out, int B, int dim, tdx_stream_t stream) {
   if (!t || !out || B <= 0 || dim < 4) return TDX_E_BADARG;
   if ((int64_t)B * dim >= (1ll << 31)) return TDX_E_SHAPE;
-  sinusoid_kernel<<<cdiv((int64_t)B * dim, 256), 256, 0, to_stream(stream)>>>(t, out, B, dim);
+  sinusoid_kernel<int64_t><<<cdiv((int64_t)B * dim, 256), 256, 0, to_stream(stream)>>>(t, out, B, dim);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same for floating-point timesteps (the reference takes `timesteps[:, None].float()`, so a fractional
+// t - a guidance / interpolation utility - keeps its fraction)
+extern "C" int tdx_timestep_embedding_f32(const float* t, float* out, int B, int dim, tdx_stream_t stream) {
+  if (!t || !out || B <= 0 || dim < 4) return TDX_E_BADARG;
+  if ((int64_t)B * dim >= (1ll << 31)) return TDX_E_SHAPE;
+  sinusoid_kernel<float><<<cdiv((int64_t)B * dim, 256), 256, 0, to_stream(stream)>>>(t, out, B, dim);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -163,12 +174,40 @@ linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ w,
   }
 }
 
-// out = act(in) W^T + b (+ addend) for an input width td = 256 R, R = 1..4 (time_dim is a constructor
-// argument of the reference's NoiseModel: diffusion.py:16, conditional_diffusion_laion.py:236)
+// Any width (time_dim is a constructor argument of the reference's NoiseModel and nothing in
+// diffusion.py:16-25 / conditional_diffusion_laion.py:236-243 restricts it): one thread per (sample, output),
+// scalar loads.  Widths that are not a multiple of 256 are not performance cases; the multiples up to 1024
+// (the reference's 256 and 768 among them) take the row kernels above.
+template <bool IN_SILU>
+__global__ void linear_generic_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                      const float* __restrict__ b, const float* __restrict__ addend,
+                                      float* __restrict__ out, int B, int O, int J) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * O) return;
+  const int n = idx / O, o = idx - n * O;
+  const float* x = in + (size_t)n * J;
+  const float* wr = w + (size_t)o * J;
+  float s = 0.f;
+  for (int j = 0; j < J; ++j) s = fmaf(wr[j], IN_SILU ? silu_f(x[j]) : x[j], s);
+  s += b[o];
+  if (addend) s += addend[idx];
+  out[idx] = s;
+}
+
+static inline bool td_fast(int td) { return td % 256 == 0 && td <= 1024; }
+static inline bool td_ok(int kind, int td) { return td >= (kind == 1 ? 4 : 1) && td <= 4096; }
+
+// out = act(in) W^T + b (+ addend) for an input width td
 template <bool IN_SILU>
 static int linear_rows(const float* in, const float* w, const float* b, const float* addend, float* out, int B,
                        int O, int td, hipStream_t st) {
   constexpr int NB = 4;
+  if (!td_fast(td) || O % 64) {
+    if ((int64_t)B * O >= (1ll << 31)) return TDX_E_SHAPE;
+    linear_generic_kernel<IN_SILU><<<cdiv((int64_t)B * O, 256), 256, 0, st>>>(in, w, b, addend, out, B, O, td);
+    TDX_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(cdiv(B, NB), O / 64);
   switch (td / 256) {
     case 1: linear_rows_kernel<1, NB, IN_SILU><<<grid, 256, 0, st>>>(in, w, b, addend, out, B, O); break;
@@ -184,7 +223,7 @@ static int linear_rows(const float* in, const float* w, const float* b, const fl
 static int time_embed_fwd_laion(const int64_t* t, const float* cond, const float* const* P, float* sin,
                                 float* pre, float* emb, float* t1, float* t2, float* t3, int B, int td,
                                 hipStream_t st) {
-  sinusoid_kernel<<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(t, sin, B, td);
+  sinusoid_kernel<int64_t><<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(t, sin, B, td);
   TDX_CHECK_LAUNCH();
   int rc = linear_rows<false>(sin, P[TDX_P_TE0_W], P[TDX_P_TE0_B], nullptr, pre, B, td, td, st);
   if (rc) return rc;
@@ -246,7 +285,7 @@ int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float
                        const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
                        float* t3, int B, hipStream_t st, int td) {
   if (td <= 0) td = kind == 1 ? TDL : TD;
-  if (td % 256 || td > 1024) return TDX_E_SHAPE;
+  if (!td_ok(kind, td)) return TDX_E_SHAPE;
   if (kind == 1) return time_embed_fwd_laion(t, cond, P, sin, pre, emb, t1, t2, t3, B, td, st);
   if (td != TD) return time_embed_fwd_generic0(t, y, P, sin, pre, emb, t1, t2, t3, B, td, st);
   time_emb_kernel<<<dim3(B, 4), 256, 0, st>>>(t, y, P[TDX_P_TE0_W], P[TDX_P_TE0_B], P[TDX_P_TE2_W],
@@ -300,9 +339,10 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
   __shared__ float red[2][8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + cl;
+  const bool live = j < td;   // any width: the last workgroup may be ragged
   float sw = 0.f, sb = 0.f;
 #pragma unroll 4
-  for (int n = sl; n < B; n += 8) {
+  for (int n = sl; n < B && live; n += 8) {
     const float gp = g_h[(size_t)n * td + j] * silu_grad_f(pre[(size_t)n * td + j]);
     // agent-scope load: served by the coherent point, whatever line of this address the XCD's L2 may hold.  The
     // one unexplained miscompute of this path was exactly ONE 128-byte line of the step indices read wrong by one
@@ -317,8 +357,10 @@ time_l1_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ pre,
     sw = 0.f; sb = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sw += red[0][k][cl]; sb += red[1][k][cl]; }
-    dw1[j] = sw;
-    db1[j] = sb;
+    if (live) {
+      dw1[j] = sw;
+      db1[j] = sb;
+    }
   }
 }
 
@@ -420,8 +462,14 @@ time_l1_bwd_i64_dbg_kernel(const float* __restrict__ g_h, const float* __restric
 }
 int g_tdx_time_l1_impl = 0;
 int g_tdx_probe_stamp = 0;
-unsigned* g_tdx_diag_buffer = nullptr;  // >= (64*8 + 8*2048) dwords, set by tdx_diag_set_buffer
-extern "C" int tdx_diag_set_buffer(void* p) { g_tdx_diag_buffer = static_cast<unsigned*>(p); return 0; }
+unsigned* g_tdx_diag_buffer = nullptr;  // set by tdx_diag_set_buffer together with its size:
+size_t g_tdx_diag_bytes = 0;            // every diagnostic path checks what it is about to write against it
+extern "C" int tdx_diag_set_buffer(void* p, size_t bytes) {
+  if (p && !bytes) return TDX_E_BADARG;
+  g_tdx_diag_buffer = static_cast<unsigned*>(p);
+  g_tdx_diag_bytes = p ? bytes : 0;
+  return 0;
+}
 
 // g[i] *= silu'(pre[i])
 __global__ void silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ pre, int n) {
@@ -523,7 +571,8 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
     TDX_CHECK_LAUNCH();
   }
   if (!(parts & TDX_TIME_L1)) return 0;
-  if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer && td == TD)
+  if (g_tdx_time_l1_impl == 2 && t_i64 && g_tdx_diag_buffer && td == TD &&
+      g_tdx_diag_bytes >= (64 * 8 + 8 * 2048) * sizeof(unsigned))   // what the instrumented kernel records
     time_l1_bwd_i64_dbg_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B,
                                                         g_tdx_diag_buffer);
   else if (g_tdx_time_l1_impl == 1 && t_i64 && td == TD)
@@ -531,7 +580,7 @@ int tdx_time_embed_bwd_ex(const float* tf, const int64_t* y, const float* const*
   else if (g_tdx_time_l1_impl == 3 && t_i64 && td == TD)
     time_l1_bwd_i64_coherent_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, t_i64, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B);
   else
-    time_l1_bwd_kernel<<<td / 32, 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, td);
+    time_l1_bwd_kernel<<<cdiv(td, 32), 256, 0, st>>>(g_h, pre, tf, G[TDX_P_TE0_W], G[TDX_P_TE0_B], B, td);
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -541,7 +590,7 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
                        const float* g_t2, const float* g_t3, float* scratch, int B, int ncls,
                        hipStream_t st, int td, int parts) {
   if (td <= 0) td = kind == 1 ? TDL : TD;
-  if (td % 256 || td > 1024) return TDX_E_SHAPE;
+  if (!td_ok(kind, td)) return TDX_E_SHAPE;
   if (kind == 1)
     return time_embed_bwd_laion(P, G, sin, pre, emb, g_t1, g_t2, g_t3, scratch, B, td, st, parts);
   const float* gk[3] = {g_t1, g_t2, g_t3};
@@ -556,7 +605,7 @@ int tdx_time_embed_bwd(int kind, const int64_t* t, const int64_t* y, const float
 int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
                       const float* g_tk, float* scratch, int B, hipStream_t st, int td) {
   if (td <= 0) td = kind == 1 ? TDL : TD;
-  if (k < 0 || k > 2 || td % 256 || td > 1024) return TDX_E_SHAPE;
+  if (k < 0 || k > 2 || !td_ok(kind, td)) return TDX_E_SHAPE;
   const int w = (kind == 1 ? 64 : 128) << k;
   const int pw = k == 0 ? TDX_P_TP1_W : k == 1 ? TDX_P_TP2_W : TDX_P_TP3_W;
   lin_wgrad_kernel<<<cdiv(w * td, 256), 256, 0, st>>>(g_tk, emb, G[pw], G[pw + 1], B, w, td, w);

@@ -72,9 +72,10 @@ constexpr int TDX_KCOUNT = 1024;
 bool make_spec(int kind, int hw, int time_dim, NetSpec* out) {
   NetSpec S = SPECS[kind];
   // time_dim is a constructor argument of the reference's NoiseModel (diffusion.py:16,
-  // conditional_diffusion_laion.py:236); the time-path kernels take multiples of 256 up to 1024
+  // conditional_diffusion_laion.py:236): any width (multiples of 256 up to 1024 run on the row kernels of
+  // time_embed.hip, everything else on its generic ones; the sinusoidal embedding needs 4 columns)
   if (time_dim > 0) {
-    if (time_dim % 256 || time_dim > 1024) return false;
+    if (time_dim > 4096 || (kind == 1 && time_dim < 4)) return false;
     S.time_dim = time_dim;
   }
   if (hw <= 0 || hw == S.hw0) { *out = S; return true; }
@@ -185,6 +186,7 @@ struct tdx_unet {
   int saved_batch, saved_mode;  // state of the last forward (for backward)
   // backward state that survives between tdx_unet_backward calls that split the stages:
   float* g_next;                // where the gradient w.r.t. the next unit's activation lives
+  float* g_x;                   // one-shot request: d loss / d x written by the last backward stage (null: not asked)
   struct GBuf { float* p; int w_unit; int s2; int age; } gb[4];  // rotating gradient buffers + last readers
   int clock;
   bool red_pending[13];         // slab reduction of unit i enqueued (third stream) and not yet waited for
@@ -263,6 +265,7 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   u->saved_batch = 0;
   u->saved_mode = -1;
   u->g_next = nullptr;
+  u->g_x = nullptr;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
   u->materialize = g_tdx_materialize != 0;
@@ -966,6 +969,10 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
         if (g_tdx_time_stage != 6) RC(time_path_bwd(st));
         RC(tdx_initial_conv_wgrad(ws + L.x, g_next, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
                                   S.hw0, S.in_ch, S.x0_real, st));
+        if (u->g_x) {   // d loss / d x, on request only (tdx_unet_request_input_grad)
+          RC(tdx_initial_conv_dgrad(g_next, P[TDX_P_INIT_W], u->g_x, B, S.hw0, S.hw0, S.in_ch, S.x0_real, st));
+          u->g_x = nullptr;
+        }
         break;
     }
   }
@@ -991,6 +998,13 @@ extern "C" int tdx_unet_eval_step(tdx_unet* u, const void* const* params, void* 
   // elementwise, so x is updated in place; both kernels skip the noise term at t == 0
   if (z) return tdx_p_sample_step(x, x, eps, z, coef, t_idx, n_elems, stream);
   return tdx_p_sample_step_philox(x, x, eps, coef, t_idx, n_elems, philox_seed, stream);
+}
+
+extern "C" int tdx_unet_request_input_grad(tdx_unet* u, float* g_x) {
+  if (!u) return TDX_E_BADARG;
+  if (!u->spec) return g_x ? TDX_E_SHAPE : 0;
+  u->g_x = g_x;
+  return 0;
 }
 
 extern "C" int tdx_unet_backward_join(tdx_unet* u, tdx_stream_t stream) {

@@ -175,11 +175,11 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, mode, x, t, y, *params):
         # grad mode is off inside Function.forward, so the caller decides the mode
-        if x.requires_grad:
-            # the reference's module is differentiable in x; this path stops at the parameters
-            # (the input gradient of initial_conv is never formed): refuse rather than return None
-            raise _lib.TdxError("x.requires_grad: libtdx computes parameter gradients only (no d/dx of the "
-                                "noise predictor); detach the input")
+        if x.requires_grad and module._arch.kind == KIND_LATENT:
+            raise _lib.TdxError("x.requires_grad: the latent MLP computes parameter gradients only; detach the input")
+        # the reference's module is differentiable in x like any nn.Module (diffusion.py:109-162): the UNets
+        # form d loss / d x on request (the input gradient of initial_conv, one extra launch)
+        ctx.x_grad = bool(x.requires_grad)
         out, plan, mode = module._run_forward(x, t, y, mode=mode)
         module._live_ctx.add(ctx)   # weak: a graph dropped without backward() leaves by itself
         ctx.module = module
@@ -197,6 +197,10 @@ class _UNetFunction(torch.autograd.Function):
                 "backward() after another forward() on the same batch size: the saved "
                 "activations live in a per-batch-size workspace and were overwritten")
         flat, views = module._grad_buffers(d_out.device)
+        gx = None
+        if ctx.x_grad:
+            gx = torch.empty((plan.batch,) + tuple(d_out.shape[1:]), dtype=torch.float32, device=d_out.device)
+            check(lib.tdx_unet_request_input_grad(plan.handle, gx.data_ptr()), "tdx_unet_request_input_grad")
         module._run_backward(plan, d_out.contiguous(), views)
         # The gradients are views of ONE module-wide flat buffer.  With a single forward in the graph
         # autograd copies them into p.grad before anything can overwrite the buffer; with several
@@ -206,7 +210,7 @@ class _UNetFunction(torch.autograd.Function):
         shared = len(module._live_ctx) > 1
         module._live_ctx.discard(ctx)
         grads = tuple(views[name].clone() if shared else views[name] for name in module._param_order)
-        return (None, None, None, None, None) + grads
+        return (None, None, gx, None, None) + grads
 
 
 class NoiseModelBase(nn.Module):
@@ -216,10 +220,13 @@ class NoiseModelBase(nn.Module):
     def __init__(self, time_dim: Optional[int] = None, num_classes: int = 0, arch: _Arch = ARCH_MNIST):
         super().__init__()
         time_dim = arch.time_dim if time_dim is None else int(time_dim)
-        # the reference accepts any width (diffusion.py:16-25); the time-path kernels read rows as
-        # 256-float segments: multiples of 256 up to 1024 (the latent MLP: its default only)
-        if time_dim % 256 or not 256 <= time_dim <= 1024 or (arch.kind == KIND_LATENT and time_dim != arch.time_dim):
-            raise ValueError(f"time_dim must be a multiple of 256 in [256, 1024] (reference default {arch.time_dim})")
+        # the reference accepts any width (diffusion.py:16-25): so do the UNets (multiples of 256 up to 1024
+        # on the fast row kernels, anything else up to 4096 on generic ones; the sinusoidal embedding of the
+        # LAION model needs 4 columns).  The latent MLP's fused kernels are built for its default only.
+        lo = 4 if arch.kind == KIND_LAION else 1
+        if not lo <= time_dim <= 4096 or (arch.kind == KIND_LATENT and time_dim != arch.time_dim):
+            raise ValueError(f"time_dim must be in [{lo}, 4096] (reference default {arch.time_dim}; the latent "
+                             "model takes its default only)")
         if arch.kind == KIND_LAION and num_classes:
             raise ValueError("the LAION model is conditioned on text embeddings, not class labels")
         self.time_dim = time_dim
@@ -342,7 +349,7 @@ class NoiseModelBase(nn.Module):
             check(lib.tdx_unet_set_bn_sync(plan.handle, None, None, None), "tdx_unet_set_bn_sync")
         else:
             if self._bn_buf is None or self._bn_buf.device != device:
-                self._bn_buf = torch.zeros(2 * 1024 + 8, dtype=torch.float64, device=device)
+                self._bn_buf = torch.zeros(2 * 1024 + 8, dtype=torch.float64, device=device)   # 2C + 1, C <= 1024
             check(lib.tdx_unet_set_bn_sync(plan.handle, C.cast(want, C.c_void_p), None, self._bn_buf.data_ptr()),
                   "tdx_unet_set_bn_sync")
         plan.bn_sync = want
@@ -511,7 +518,7 @@ class NoiseModelBase(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _forward_impl(self, x, t, y):
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if not needs_grad or (x.shape[0] == 0 and not self.training):
             return self._run_forward(x, t, y)[0]
         d = dict(self.named_parameters())

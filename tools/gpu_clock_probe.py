@@ -13,7 +13,7 @@ from tiny_diffusion_amd._lib import lib, check
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 stamps = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
-lib.tdx_diag_set_buffer(stamps.data_ptr())
+lib.tdx_diag_set_buffer(stamps.data_ptr(), stamps.numel() * stamps.element_size())
 B = 256
 out = {}
 
@@ -85,6 +85,6 @@ for cin, cout, H in ((512, 128, 16), (1024, 256, 8), (128, 128, 28), (256, 256, 
         lambda: check(lib.tdx_conv3x3_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, H, cin, cout, 4,
                                           None, None, None, None, stat.data_ptr(), st)),
         nwg, 2.0 * M * 9 * cin * cout)
-lib.tdx_diag_set_buffer(None)
+lib.tdx_diag_set_buffer(None, 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/clock_probe.json", "w"), indent=1)

@@ -15,7 +15,7 @@ m = NoiseModel().cuda().train()
 ts = TrainStep(m, ForwardProcess(), philox_seed=1)
 x0 = torch.rand(256, 1, 28, 28, device="cuda") * 2 - 1
 stamps = torch.zeros(16 * 8 * 8192, dtype=torch.int64, device="cuda")
-lib.tdx_diag_set_buffer(stamps.data_ptr())
+lib.tdx_diag_set_buffer(stamps.data_ptr(), stamps.numel() * stamps.element_size())
 for _ in range(30):
     ts.step(x0)
 torch.cuda.synchronize()
@@ -38,7 +38,7 @@ if sel == 2:   # every training-forward conv of one step, absolute 100 MHz times
         print(f"conv #{k:2d}: {len(r):5d} wgs, first loop start {float(st_):8.1f}, last loop end {float(en_):8.1f}, last epilogue end "
               f"{float(ep_):8.1f} (in-kernel {float(ep_ - st_):6.1f} us){gap}")
         prev_end = ep_
-    lib.tdx_diag_set_buffer(None)
+    lib.tdx_diag_set_buffer(None, 0)
     sys.exit(0)
 s = stamps.cpu().view(-1, 8).double()
 s = s[s[:, 1] > 0]
@@ -53,4 +53,4 @@ for x in range(8):
     sel_ = s[xcc == x]
     if len(sel_):
         print(f"  xcc {x}: n={len(sel_)} loop med {float(sel_[:, 1].median() / 100):.1f} us start med {float((sel_[:, 2].median() - t0) / 100):.1f}")
-lib.tdx_diag_set_buffer(None)
+lib.tdx_diag_set_buffer(None, 0)

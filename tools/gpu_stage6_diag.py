@@ -138,7 +138,7 @@ def arm(name, l1_impl, input_copy, stage, destroy_while_running=True):
 
 # instrumented variant first: what did the kernel actually load?
 dbg = torch.zeros(64 * 8 + 8 * 2048, dtype=torch.int32, device="cuda")
-lib.tdx_diag_set_buffer(dbg.data_ptr())
+lib.tdx_diag_set_buffer(dbg.data_ptr(), dbg.numel() * dbg.element_size())
 
 
 def dump_seen(t_true):
@@ -162,7 +162,7 @@ DUMP = dump_seen
 out = ([] if os.environ.get("TDX_DIAG_SKIP_INSTRUMENTED") else [arm("instrumented old kernel, stage 6", 2, 0, 6)]) + [
     arm("old-kernel+hipMemcpyAsync, stage 6", 1, 0, 6)] + (
     [arm("old kernel with agent-scope atomic loads of t, stage 6", 3, 0, 6)] if os.environ.get("TDX_DIAG_COHERENT") else [])
-lib.tdx_diag_set_buffer(None); lib.tdx_tune_set(b"time_stage_diag", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
+lib.tdx_diag_set_buffer(None, 0); lib.tdx_tune_set(b"time_stage_diag", 14); lib.tdx_tune_set(b"time_l1_impl", 0); lib.tdx_tune_set(b"input_copy", 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/stage6_diag.json", "w"), indent=1)
 print(json.dumps([{k: v for k, v in o.items() if k != "report"} for o in out]))

@@ -12,7 +12,7 @@ from tiny_diffusion_amd._lib import lib, check
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 stamps = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
-lib.tdx_diag_set_buffer(stamps.data_ptr())
+lib.tdx_diag_set_buffer(stamps.data_ptr(), stamps.numel() * stamps.element_size())
 B = 256
 for cin, cout, H in ((128, 128, 28), (64, 128, 28), (256, 256, 14), (512, 512, 7), (256, 64, 32), (64, 64, 32)):
     M = B * H * H
@@ -64,4 +64,4 @@ for cin, cout, H in ((128, 128, 28), (64, 128, 28), (256, 256, 14), (512, 512, 7
     print(f"{cin}->{cout} @{H} tile {bm}x{bn}: {int(s.shape[0])} wgs, span {float(span):.1f} us, resident/CU {float(life.sum() / span / 256):.2f}, "
           f"in-loop/CU {float(((l1 - l0) / 100).sum() / span / 256):.2f}, prologue {med((l0 - entry) / 100):.1f} us, loop {med((l1 - l0) / 100):.1f}, "
           f"epilogue {med((end - l1) / 100):.1f}, distinct (xcc,se,sh,cu) {int(cu.unique().numel())}", flush=True)
-lib.tdx_diag_set_buffer(None)
+lib.tdx_diag_set_buffer(None, 0)
