@@ -637,3 +637,41 @@ def test_train_step_graph_capture_three_streams():
     # (lr / bias-correction scalars are rounded to fp32 on the host in graph mode, in C in eager mode: elements
     # whose |g| ~ eps move by a different fraction of a step; lr = 1e-4)
     assert (p0 - p1).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("cond,training,B", [(False, True, 33), (True, False, 7), (False, True, 256)])
+def test_bn_backward_fused_partials_match_reduction_pass(cond, training, B):
+    """The BatchNorm-backward partial sums emitted by the kernels that PRODUCE each activation gradient (the
+    input-gradient convolutions' epilogue, the resize adjoint, the max-pool backward; knob bnbwd_fused = 1, the
+    default) against the separate reduction pass over (g, y) they replace (bnbwd_fused = 0): the same sums in
+    another grouping, so every parameter gradient agrees to fp32 rounding (and both runs are deterministic)."""
+    from tiny_diffusion_amd._lib import lib
+
+    g = torch.Generator().manual_seed(900 + B)
+    x = torch.randn(B, 1, 28, 28, generator=g).cuda()
+    noise = torch.randn(B, 1, 28, 28, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    y = torch.randint(0, 10, (B,), generator=g).cuda() if cond else None
+    args = (x, t) + ((y,) if cond else ())
+    grads = {}
+    try:
+        for fused in (1, 0, 1):
+            assert lib.tdx_tune_set(b"bnbwd_fused", fused) == 0
+            m = build(cond, 17).train(training)
+            F.mse_loss(m(*args), noise).backward()
+            cur = {k: p.grad.clone() for k, p in m.named_parameters()}
+            if fused in grads:   # the fused path is reproducible bit for bit
+                for k in cur:
+                    assert torch.equal(cur[k], grads[fused][k]), k
+            grads[fused] = cur
+    finally:
+        lib.tdx_tune_set(b"bnbwd_fused", 1)
+    worst = 0.0
+    for k in grads[0]:
+        if training and is_pre_bn_bias(k):
+            continue
+        a, b = grads[1][k].double(), grads[0][k].double()
+        err = (a - b).norm().item() / max(b.norm().item(), 1e-30)
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err)
+    print(f"fused vs reduction-pass BN backward, B={B} cond={cond} training={training}: worst rel. diff {worst:.2e}")

@@ -5,6 +5,7 @@
 // (relu(y*scale+shift)), so the normalised activation is never written to HBM.
 // Backward: two per-channel reductions over (g, y), then one in-place pass.
 #include "internal.h"
+#include <algorithm>
 
 #define BN_EPS 1e-5f
 #define BN_MOMENTUM 0.1f
@@ -421,7 +422,12 @@ bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t 
 
 extern "C" size_t tdx_bn_relu_bwd_scratch_floats(int64_t rows, int C) {
   if (rows <= 0 || C <= 0 || C % 4 || C > 1024 || (256 % (C / 4)) != 0) return 0;
-  return (size_t)cdiv(rows, bwd_rows_per_block(rows, C)) * 2 * C + 3 * (size_t)C;
+  // room for whichever kernel writes the partial rows: the reduction pass below, a convolution epilogue (one row per
+  // tile of >= 64 pixels) or a spatial producer (at most TDX_BNBWD_MAX_PRODUCER_BLOCKS workgroups)
+  size_t nblk = (size_t)cdiv(rows, bwd_rows_per_block(rows, C));
+  nblk = std::max(nblk, (size_t)cdiv(rows, 64));
+  nblk = std::max(nblk, (size_t)TDX_BNBWD_MAX_PRODUCER_BLOCKS);
+  return nblk * 2 * C + 3 * (size_t)C;
 }
 
 extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, const float* scale,
@@ -452,6 +458,21 @@ int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const fl
   bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
       g, y, rows, C, scale, shift, save_mean, save_rstd, partial, rpb);
   TDX_CHECK_LAUNCH();
+  return tdx_bn_relu_bwd_tail(g, y, rows, C, scale, shift, save_mean, save_rstd, gamma, dgamma, dbeta, dbias, partial,
+                              nblk, coef, training, sync, sync_user, mom, stream);
+}
+
+// Finalize + apply from partial sums [nblk][2][C] that are already in memory: written by the reduction kernel
+// above, or by the kernel that produced g (conv_epilogue EPI_BNBWD, bilinear_bwd_rows / maxpool_bwd with the BN
+// operands), in which case no reduction pass runs at all.
+int tdx_bn_relu_bwd_tail(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
+                         float* dbeta, float* dbias, const float* partial, int nblk, float* coef, int training,
+                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream) {
+  if (!g || !y || !partial || !coef || nblk <= 0 || rows <= 0) return TDX_E_BADARG;
+  if (sync && (!mom || !training)) return TDX_E_BADARG;
+  if (C % 4 || C > 1024) return TDX_E_SHAPE;
+  hipStream_t st = to_stream(stream);
   if (sync) {
     bn_bwd_sums_kernel<<<cdiv(C, 4), 256, 0, st>>>(partial, nblk, (double)rows, C, dgamma, dbeta, dbias, mom);
     TDX_CHECK_LAUNCH();

@@ -697,6 +697,7 @@ static int g_splitk_train_any = 0;      // 1: also shapes whose picked tile is 1
 static int g_wgrad_plan = 1;          // 0: round-1 targets; 1: the same, split count rounded down to two whole rounds of slots;
                                       // 2: tile and rounds by a cost model (experiments: best isolated, worse inside the step)
 static int g_wgrad_rounds = 0;        // experiments: force that many rounds in pick_wgrad (0: cheapest by its cost model)
+#define TDX_CONV_OUT_BNBWD 8   /* internal flag: the epilogue emits BatchNorm-backward partial sums (ConvArgs::bw_*) */
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
@@ -733,6 +734,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "bnbwd_fused")) { g_tdx_bnbwd_fused = value & 7; return 0; }
   if (!strcmp(key, "conv_hybrid")) { g_conv_hybrid = value != 0; return 0; }
   if (!strcmp(key, "splitk_fused")) { g_splitk_fused = value != 0; return 0; }
   if (!strcmp(key, "splitk_train")) { g_splitk_train = value != 0; return 0; }
@@ -781,7 +783,9 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
   const bool in_bn = flags & TDX_CONV_IN_BNRELU;
   const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU
                   : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS
+                  : (flags & TDX_CONV_OUT_BNBWD) ? EPI_BNBWD
                                                  : EPI_PLAIN;
+  if (epi == EPI_BNBWD && (in_bn || !g_conv_dma)) return TDX_E_BADARG;  // input-gradient launches read a raw tensor
 #define TDX_LAUNCH_DMA(EPI_)                                                                \
   do {                                                                                      \
     auto kern = conv3x3_igemm_dma_kernel<BM, BN, EPI_>;                                     \
@@ -791,6 +795,7 @@ static int launch_conv(const ConvArgs& a, int flags, hipStream_t st) {
   if (!in_bn && g_conv_dma) {
     if (epi == EPI_BNRELU) TDX_LAUNCH_DMA(EPI_BNRELU);
     else if (epi == EPI_STATS) TDX_LAUNCH_DMA(EPI_STATS);
+    else if (epi == EPI_BNBWD) TDX_LAUNCH_DMA(EPI_BNBWD);
     else TDX_LAUNCH_DMA(EPI_PLAIN);
     TDX_CHECK_LAUNCH();
     return 0;
@@ -1044,6 +1049,10 @@ extern "C" int tdx_conv3x3_shape_ok(int B, int H, int W, int cin, int cout) {
          (int64_t)cout * 9 * cin * 4 < (1ll << 31);
 }
 
+// extra operands of the EPI_BNBWD epilogue (set by tdx_conv3x3_dgrad_bnbwd around its call; host-side only)
+struct BwOperands { const float *y, *scale, *shift, *mean, *rstd; float* partial; };
+static thread_local BwOperands g_bw = {};
+
 static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias, float* out,
                             int B, int H, int W, int cin, int cout, int flags,
                             const float* in_scale, const float* in_shift,
@@ -1064,6 +1073,11 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
   a.in = in; a.w = wpk; a.bias = bias; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
   a.stats = (flags & TDX_CONV_OUT_STATS) ? stats_partial : nullptr;
+  if (flags & TDX_CONV_OUT_BNBWD) {
+    if (!g_bw.y || !g_bw.partial || (flags & (TDX_CONV_OUT_STATS | TDX_CONV_OUT_BNRELU | TDX_CONV_IN_BNRELU))) return TDX_E_BADARG;
+    a.bw_y = g_bw.y; a.bw_scale = g_bw.scale; a.bw_shift = g_bw.shift; a.bw_mean = g_bw.mean; a.bw_rstd = g_bw.rstd;
+    a.bw_partial = g_bw.partial;
+  }
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   TileCfg c = pick_tile(M64, cout);
   a.tilesN = cout / c.bn;
@@ -1138,6 +1152,30 @@ extern "C" int tdx_conv3x3_fwd_train(const float* in, const float* wpk, const fl
   if (flags & ~TDX_CONV_OUT_STATS) return TDX_E_BADARG;
   return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, nullptr, nullptr, nullptr, nullptr,
                           stats_partial, scratch, scratch_floats, stream, true);
+}
+
+// The input gradient of a unit (tdx_conv3x3_fwd_train with flags = 0 on the dgrad pack) whose result is
+// dL/d(activation) of the unit below: also emits that unit's BatchNorm-backward partial sums from the epilogue
+// (ConvArgs::bw_*).  *nblk = number of partial rows written ([nblk][2][cout], rows of `*tile_rows` pixels), or 0
+// when this shape runs on a path without the fused epilogue (split-K: the caller then runs the reduction pass).
+int tdx_conv3x3_dgrad_bnbwd(const float* in, const float* wpk, float* out, int B, int H, int W, int cin, int cout,
+                            const float* y, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, float* partial, int* nblk, float* scratch, size_t scratch_floats,
+                            tdx_stream_t stream) {
+  *nblk = 0;
+  const int64_t M = (int64_t)B * H * W;
+  int per;
+  if (!(g_tdx_bnbwd_fused & 1) || !g_conv_dma || !y || !partial || cin % BK || cout % 64 || M >= (1ll << 31) ||
+      plan_splitk_train(M, cin, cout, &per, scratch_floats) > 1 || g_conv_hybrid)
+    return conv3x3_fwd_impl(in, wpk, nullptr, out, B, H, W, cin, cout, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            scratch, scratch_floats, stream, true);
+  g_bw = {y, scale, shift, mean, rstd, partial};
+  const int rc = conv3x3_fwd_impl(in, wpk, nullptr, out, B, H, W, cin, cout, TDX_CONV_OUT_BNBWD, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr, 0, stream, false);
+  g_bw = {};
+  if (rc) return rc;
+  *nblk = cdiv(M, pick_tile(M, cout).bm);
+  return 0;
 }
 
 extern "C" int tdx_conv3x3_fwd_splitk(const float* in, const float* wpk, const float* bias, float* out,

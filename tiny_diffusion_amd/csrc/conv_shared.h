@@ -4,7 +4,7 @@
 #pragma once
 #include "internal.h"
 
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BNRELU = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_BNRELU = 2, EPI_BNBWD = 3 };
 
 struct ConvArgs {
   const float* in;
@@ -30,6 +30,15 @@ struct ConvArgs {
   // raw partials to hyb_scratch[slice][row - hyb_row0][Cout]; hyb_sp = 0: off (conv3x3.hip, plan_hybrid)
   int hyb_full, hyb_sp, hyb_row0;
   float* hyb_scratch;
+  // EPI_BNBWD (input-gradient launches of the backward): the tensor this launch writes is dL/d(activation) of the
+  // unit BELOW, whose BatchNorm+ReLU backward comes next and starts with two per-channel reductions over
+  // (this gradient, that unit's pre-BN output y).  The accumulators are still in registers here, so the epilogue
+  // reads the matching y tile and emits the per-tile partial sums [tilesM][2][Cout] (sum gz, sum gz*xhat; gz = the
+  // gradient where relu(bn(y)) is active) - the format bn_bwd_finalize reads - and the separate reduction pass
+  // (8 B/element over both tensors + a launch on the backward's dependent chain) is not run.
+  const float* bw_y;
+  const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_rstd;
+  float* bw_partial;
   unsigned long long* stamps;  // diagnostics (tools/gpu_clock_probe.py): per workgroup {shader cycles, 100 MHz ticks}
                                // around the main loop; null in every product launch
 };
@@ -103,6 +112,56 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
       }
       *reinterpret_cast<float4*>(a.final_out + (size_t)p * a.Cout + col) = v;
+    }
+    return;
+  }
+  if (EPI == EPI_BNBWD) {
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = n0 + wn * WTN + in * 32 + l31;
+      const float bv = a.bias ? a.bias[col] : 0.f;
+      const float sc = a.bw_scale[col], sh = a.bw_shift[col], mu = a.bw_mean[col], rs = a.bw_rstd[col];
+      float yv[TM][16];
+#pragma unroll
+      for (int im = 0; im < TM; ++im)   // all of the tile's y loads in flight together
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          yv[im][r] = p < a.M ? a.bw_y[(size_t)p * a.Cout + col] : 0.f;
+        }
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float v = acc[im][in][r] + bv;
+          if (p < a.M) {
+            a.out[(size_t)p * a.Cout + col] = v;
+            const float gz = fmaf(yv[im][r], sc, sh) > 0.f ? v : 0.f;   // the mask of bn_bwd_reduce / bn_bwd_apply
+            a1 += gz;
+            a2 += gz * ((yv[im][r] - mu) * rs);
+          }
+        }
+      s1[in] = a1 + __shfl_xor(a1, 32, 64);
+      s2[in] = a2 + __shfl_xor(a2, 32, 64);
+    }
+    float* red = smem;  // [2][WGM][BN], re-uses the tile buffers (K loop is over)
+    __syncthreads();    // every wave is done with the tile buffers
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+      if (half == 0) {
+        red[(0 * WGM + wm) * BN + wn * WTN + in * 32 + l31] = s1[in];
+        red[(1 * WGM + wm) * BN + wn * WTN + in * 32 + l31] = s2[in];
+      }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int q = c / BN, cc = c - q * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) v += red[(q * WGM + w) * BN + cc];   // fixed order: deterministic
+      a.bw_partial[((size_t)tile_m * 2 + q) * a.Cout + n0 + cc] = v;
     }
     return;
   }

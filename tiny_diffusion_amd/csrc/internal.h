@@ -94,6 +94,30 @@ int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const flo
 // written out (post BN+ReLU) so that convolution and its wgrad run on the LDS-DMA kernels
 extern int g_tdx_materialize;
 extern int g_tdx_time_stage;
+// tuning knob "bnbwd_fused": 1 = the kernel that PRODUCES dL/d(activation) of a unit (the input-gradient
+// convolution of the unit above, the resize adjoint or the max-pool backward) also emits the partial sums of that
+// unit's BatchNorm backward, and the separate reduction pass is skipped (unet.hip, tdx_unet_backward)
+extern int g_tdx_bnbwd_fused;
+int tdx_conv3x3_dgrad_bnbwd(const float* in, const float* wpk, float* out, int B, int H, int W, int cin, int cout,
+                            const float* y, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, float* partial, int* nblk, float* scratch, size_t scratch_floats,
+                            tdx_stream_t stream);
+// BatchNorm+ReLU backward from partial sums a producer kernel has already written ([nblk][2][C] at `partial`;
+// coef: 3*C floats of scratch): finalize + apply, the tail of tdx_bn_relu_bwd_sync
+int tdx_bn_relu_bwd_tail(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
+                         float* dbeta, float* dbias, const float* partial, int nblk, float* coef, int training,
+                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream);
+// the resize adjoint / max-pool backward that also emit those partial sums for the tensor they write
+// (bn_y .. bn_rstd of the unit whose activation gradient g_in is; partial [*nblk][2][C])
+int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           int g_cstride, int g_coff, const float* bn_y, const float* bn_scale,
+                           const float* bn_shift, const float* bn_mean, const float* bn_rstd, float* partial,
+                           int* nblk, tdx_stream_t stream);
+int tdx_maxpool2_ceil_bwd_bn(const float* y, const float* scale, const float* shift, const float* g_out,
+                             const float* skip_grad, float* g_in, int B, int H, int W, int C, const float* bn_mean,
+                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream);
+#define TDX_BNBWD_MAX_PRODUCER_BLOCKS 2048   // workgroups of the two spatial producers above
 extern int g_tdx_time_proj_early;
 // inference: both halves of a decoder's concatenated input (resize(a) | resize(b + b_addend)) in one launch
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,

@@ -13,6 +13,42 @@ __device__ static inline float4 bnrelu4(float4 v, const float4& sc, const float4
   return v;
 }
 
+// BatchNorm-backward partial sums emitted by the kernel that PRODUCES dL/d(activation) of a unit (the max-pool
+// backward and the resize adjoint below; the input-gradient convolutions do the same in conv_epilogue): per
+// workgroup and channel, sum gz and sum gz * xhat over the elements the workgroup wrote, gz = the gradient where
+// relu(bn(y)) is active, xhat = (y - mean) * rstd - what bn_bwd_reduce_kernel would compute in a pass of its own
+// over both tensors.  Every thread of these kernels keeps ONE channel quad for its whole life (256 % (C/4) == 0 and
+// its stride is a multiple of 256), so the sums live in registers and meet in LDS once, in a fixed order.
+struct BnBwdOps {
+  const float* y;       // pre-BN output of the unit, same layout as the gradient being written
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+  float* partial;       // [gridDim.x][2][C]
+};
+__device__ static inline void bnbwd_acc(const float4& g, const float4& y, const float4& sc, const float4& sh,
+                                        const float4& mu, const float4& rs, float4& s1, float4& s2) {
+#define ACC(k)                                                  \
+  {                                                             \
+    const float gz = fmaf(y.k, sc.k, sh.k) > 0.f ? g.k : 0.f;   \
+    s1.k += gz;                                                 \
+    s2.k += gz * ((y.k - mu.k) * rs.k);                         \
+  }
+  ACC(x) ACC(y) ACC(z) ACC(w)
+#undef ACC
+}
+// red: 2 * 256 * 4 floats of LDS; thread t owns channels (t % c4n) * 4 .. + 3
+__device__ static inline void bnbwd_flush(float* red, const float4& s1, const float4& s2, int C, float* partial) {
+  const int c4n = C / 4, col = threadIdx.x % c4n, rg = threadIdx.x / c4n, rgroups = 256 / c4n;
+  __syncthreads();
+  *reinterpret_cast<float4*>(red + (rg * 2 + 0) * C + col * 4) = s1;
+  *reinterpret_cast<float4*>(red + (rg * 2 + 1) * C + col * 4) = s2;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float v = 0.f;
+    for (int k = 0; k < rgroups; ++k) v += red[k * 2 * C + i];
+    partial[(size_t)blockIdx.x * 2 * C + i] = v;
+  }
+}
+
 static inline int ew_grid(int64_t n, int block = 256, int cap = 4096) {
   int64_t g = (n + block - 1) / block;
   if (g > cap) g = cap;
@@ -70,13 +106,20 @@ extern "C" int tdx_maxpool2_ceil_fwd(const float* y, const float* scale, const f
 // One thread owns one 2x2 window (windows do not overlap): route the pooled
 // gradient to the FIRST maximum in scan order (ATen: `val > maxval`), add the
 // skip-path gradient, and write all (up to) four input positions.
-template <bool BN>
+template <bool BN, bool BNP = false>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                    const float* __restrict__ shift, const float* __restrict__ g_out,
                                    const float* __restrict__ skip, float* __restrict__ g_in, int B,
-                                   int H, int W, int C) {
+                                   int H, int W, int C, BnBwdOps bw = BnBwdOps{}) {
+  __shared__ __attribute__((aligned(16))) float red[BNP ? 2048 : 4];
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
   const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, rs = s1;
+  if (BNP) {
+    const int cq = (threadIdx.x % c4n) * 4;
+    mu = *reinterpret_cast<const float4*>(bw.mean + cq);
+    rs = *reinterpret_cast<const float4*>(bw.rstd + cq);
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4n) * 4;
@@ -92,11 +135,13 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
     const float4 go = *reinterpret_cast<const float4*>(g_out + i * 4);
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int arg[4] = {0, 0, 0, 0};
+    float4 yraw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
       if (ih < H && iw < W) {
         float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)b * H + ih) * W + iw) * C + c);
+        yraw[k] = v;
         if (BN) v = bnrelu4(v, sc, sh);
         if (v.x > m[0]) { m[0] = v.x; arg[0] = k; }
         if (v.y > m[1]) { m[1] = v.y; arg[1] = k; }
@@ -115,9 +160,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
         if (arg[2] == k) r.z += go.z;
         if (arg[3] == k) r.w += go.w;
         *reinterpret_cast<float4*>(g_in + off) = r;
+        if (BNP) bnbwd_acc(r, yraw[k], sc, sh, mu, rs, s1, s2);
       }
     }
   }
+  if (BNP) bnbwd_flush(red, s1, s2, C, bw.partial);
 }
 
 extern "C" int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const float* shift,
@@ -129,6 +176,22 @@ extern "C" int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const f
   if (scale) maxpool_bwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
   else maxpool_bwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
   TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_maxpool2_ceil_bwd_bn(const float* y, const float* scale, const float* shift, const float* g_out,
+                             const float* skip_grad, float* g_in, int B, int H, int W, int C, const float* bn_mean,
+                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream) {
+  *nblk = 0;
+  if (!(g_tdx_bnbwd_fused & 4) || !scale || !partial || C % 4 || C > 1024 || 256 % (C / 4))
+    return tdx_maxpool2_ceil_bwd(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, stream);
+  if (!y || !g_out || !g_in || !bn_mean || !bn_rstd || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  const int grid = ew_grid(n, 256, TDX_BNBWD_MAX_PRODUCER_BLOCKS);
+  maxpool_bwd_kernel<true, true><<<grid, 256, 0, to_stream(stream)>>>(
+      y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, BnBwdOps{y, scale, shift, bn_mean, bn_rstd, partial});
+  TDX_CHECK_LAUNCH();
+  *nblk = grid;
   return 0;
 }
 
@@ -360,13 +423,23 @@ __device__ static inline void axis_window(int i, float scale, int n_in, int n_ou
   n_out_w = last >= 0 ? last - first + 1 : 0;
 }
 
+template <bool BNP>
 __global__ void __launch_bounds__(256)
 bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_in, int rows,
                          int Hi, int Wi, int Ho, int Wo, int C, int gcs, int gcoff, float sch,
-                         float scw) {
+                         float scw, BnBwdOps bw) {
   __shared__ float s_ww[BIL_ROW_MAXW][BIL_MAXC], s_wh[BIL_ROW_MAXW][BIL_MAXC];
   __shared__ int s_wlo[BIL_ROW_MAXW], s_wn[BIL_ROW_MAXW], s_hlo[BIL_ROW_MAXW], s_hn[BIL_ROW_MAXW];
+  __shared__ __attribute__((aligned(16))) float red[BNP ? 2048 : 4];
   const int tid = threadIdx.x, c4n = C / 4, per_row = Wi * c4n;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, bsc = s1, bsh = s1, bmu = s1, brs = s1;
+  if (BNP) {   // this thread's channel quad never changes: j = tid + 256 k and 256 % c4n == 0
+    const int cq = (tid % c4n) * 4;
+    bsc = *reinterpret_cast<const float4*>(bw.scale + cq);
+    bsh = *reinterpret_cast<const float4*>(bw.shift + cq);
+    bmu = *reinterpret_cast<const float4*>(bw.mean + cq);
+    brs = *reinterpret_cast<const float4*>(bw.rstd + cq);
+  }
   // both axes' windows depend only on the index along the axis: all of them once per workgroup (Hi, Wi <= 64),
   // then rows are walked with no barrier and no tap arithmetic in the loop
   if (tid < Wi) axis_window(tid, scw, Wi, Wo, s_ww[tid], s_wlo[tid], s_wn[tid]);
@@ -420,8 +493,13 @@ bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_
         }
       }
       *reinterpret_cast<float4*>(orow + (int64_t)j * 4) = acc;
+      if (BNP) {
+        const float4 yv = *reinterpret_cast<const float4*>(bw.y + (int64_t)r * per_row * 4 + (int64_t)j * 4);
+        bnbwd_acc(acc, yv, bsc, bsh, bmu, brs, s1, s2);
+      }
     }
   }
+  if (BNP) bnbwd_flush(red, s1, s2, C, bw.partial);
 }
 
 // host-side check that BIL_MAXC candidates cover every contributor of every input index
@@ -446,14 +524,37 @@ extern "C" int tdx_bilinear_ac_bwd(const float* g_out, float* g_in, int B, int H
   const int64_t n = (int64_t)B * Hi * Wi * (C / 4);
   if (Wi <= BIL_ROW_MAXW && Hi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30)) {
     const int rows = B * Hi;
-    bilinear_bwd_rows_kernel<<<rows < 16384 ? rows : 16384, 256, 0, to_stream(stream)>>>(
-        g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+    bilinear_bwd_rows_kernel<false><<<rows < 16384 ? rows : 16384, 256, 0, to_stream(stream)>>>(
+        g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo), BnBwdOps{});
     TDX_CHECK_LAUNCH();
     return 0;
   }
   bilinear_bwd_kernel<<<ew_grid(n), 256, 0, to_stream(stream)>>>(
       g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
   TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           int g_cstride, int g_coff, const float* bn_y, const float* bn_scale,
+                           const float* bn_shift, const float* bn_mean, const float* bn_rstd, float* partial,
+                           int* nblk, tdx_stream_t stream) {
+  *nblk = 0;
+  const bool rows_form = Wi <= BIL_ROW_MAXW && Hi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30);
+  if (!(g_tdx_bnbwd_fused & 2) || !bn_y || !partial || !rows_form || C % 4 || C > 1024 || 256 % (C / 4))
+    return tdx_bilinear_ac_bwd(g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, stream);
+  if (!g_out || !g_in || !bn_scale || !bn_shift || !bn_mean || !bn_rstd || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 ||
+      Wo <= 0)
+    return TDX_E_BADARG;
+  if (g_cstride % 4 || g_coff % 4 || g_coff + C > g_cstride) return TDX_E_SHAPE;
+  if (!adjoint_window_ok(Hi, Ho) || !adjoint_window_ok(Wi, Wo)) return TDX_E_SHAPE;
+  const int rows = B * Hi;
+  const int grid = rows < TDX_BNBWD_MAX_PRODUCER_BLOCKS ? rows : TDX_BNBWD_MAX_PRODUCER_BLOCKS;
+  bilinear_bwd_rows_kernel<true><<<grid, 256, 0, to_stream(stream)>>>(
+      g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo),
+      BnBwdOps{bn_y, bn_scale, bn_shift, bn_mean, bn_rstd, partial});
+  TDX_CHECK_LAUNCH();
+  *nblk = grid;
   return 0;
 }
 

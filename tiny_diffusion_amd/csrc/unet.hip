@@ -164,6 +164,11 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+int g_tdx_bnbwd_fused = 6;     // knob "bnbwd_fused" (internal.h): bit 0 input-gradient convolutions, bit 1 resize adjoints, bit 2 max-pool backward.
+                               // Measured at B = 256 (tools/gpu_ab.py, ms/step): 0: 15.54, 1: 15.73, 2: 15.52, 4: 15.55, 6: 15.53, 7: 15.66 - the
+                               // heavier convolution epilogue costs the GEMMs more than the reduction pass it saves (that pass is HBM-bound and
+                               // runs beside the weight-gradient GEMMs of the other stream for nothing); the two spatial producers are neutral in
+                               // time and save 8 B/element of HBM traffic and a launch on seven layers: on. The convolution form stays an experiment.
 int g_tdx_time_proj_early = 1;  // time_proj backward right behind each pixel sum (0: with the rest, at the end)
 int g_tdx_time_stage = 14;  // backward stage after which the time/class path runs (14, or 6: see DESIGN.md 3.2)
 int g_tdx_input_copy = 0;
@@ -186,6 +191,7 @@ struct tdx_unet {
   int saved_batch, saved_mode;  // state of the last forward (for backward)
   // backward state that survives between tdx_unet_backward calls that split the stages:
   float* g_next;                // where the gradient w.r.t. the next unit's activation lives
+  int bw_unit, bw_nblk;         // unit whose BatchNorm-backward partial sums a producer kernel has left in bnscr (-1: none)
   float* g_x;                   // one-shot request: d loss / d x written by the last backward stage (null: not asked)
   struct GBuf { float* p; int w_unit; int s2; int age; } gb[4];  // rotating gradient buffers + last readers
   int clock;
@@ -266,6 +272,8 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   u->saved_mode = -1;
   u->g_next = nullptr;
   u->g_x = nullptr;
+  u->bw_unit = -1;
+  u->bw_nblk = 0;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent
   u->materialize = g_tdx_materialize != 0;
@@ -735,6 +743,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     for (int i = 0; i < 4; ++i) gb[i] = GBuf{base[i], -1, -1, 0};
     clock = 0;
     for (int i = 0; i < 13; ++i) u->red_pending[i] = false;
+    u->bw_unit = -1;
   } else if (gb[0].p != ws + L.G1) {
     return TDX_E_STATE;  // another workspace than the one stage 0 ran on
   }
@@ -785,10 +794,21 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     float* g = g_next;
     const float* ss = ws + L.ss[i];
     const int64_t rows = (int64_t)B * d.hw * d.hw;
-    RC(tdx_bn_relu_bwd_sync(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
-                            ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
-                            G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
-                            training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
+    if (u->bw_unit == i && u->bw_nblk > 0) {
+      // the kernel that wrote g (the input-gradient convolution of the unit above, a resize adjoint or a max-pool
+      // backward) left this unit's partial sums in bnscr: no reduction pass over (g, y)
+      RC(tdx_bn_relu_bwd_tail(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout, ss + 3 * d.cout,
+                              P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 3],
+                              G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, u->bw_nblk,
+                              ws + L.bnscr + (size_t)u->bw_nblk * 2 * d.cout, training,
+                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
+    } else {
+      RC(tdx_bn_relu_bwd_sync(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
+                              ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
+                              G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
+                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
+    }
+    u->bw_unit = -1;
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
     // NetSpec says overlap = 0).
     const bool bn_on_load = d.in_bn && (!u->materialize || bf16);
@@ -837,12 +857,23 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     if (bf16)
       RC(tdx_conv3x3_fwd_bf16(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
                               nullptr, nullptr, nullptr, nullptr, stream));
-    else
+    else if (d.in_bn) {
+      // g_in is dL/d(activation) of unit i-1 (same resolution, no pool / resize in between): its BatchNorm backward
+      // comes next, and this launch's epilogue leaves that unit's partial sums behind (nblk = 0: not on this path)
+      const float* pss = ws + L.ss[i - 1];
+      int nblk = 0;
+      RC(tdx_conv3x3_dgrad_bnbwd(g, u->wpack + u->wd_off[i], g_in, B, d.hw, d.hw, d.cout, d.cin, ws + L.Y[i - 1], pss,
+                                 pss + d.cin, pss + 2 * d.cin, pss + 3 * d.cin, ws + L.bnscr, &nblk, ws + L.ksplit,
+                                 L.ksplit_floats, stream));
+      if (nblk > 0) { u->bw_unit = i - 1; u->bw_nblk = nblk; }
+    } else
       RC(tdx_conv3x3_fwd_train(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
                                ws + L.ksplit, L.ksplit_floats, stream));
     *g_in_out = g_in;
     return 0;
   };
+  // the BatchNorm operands of unit i for a producer of its activation gradient (tdx_*_bwd_bn)
+  auto bw_y = [&](int i) -> const float* { return bf16 ? nullptr : ws + L.Y[i]; };   // null: producer stays unfused
   auto plain_unit_bwd = [&](int i, const float* in) -> int {
     float* g_in;
     RC(unit_bwd(i, in, &g_in));
@@ -891,7 +922,13 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     find(gcat)->s2 = k;
     float* gup;
     RC(acquire(gcat, nullptr, &gup));
-    RC(tdx_bilinear_ac_bwd(gcat, gup, B, dp.hw, dp.hw, da.hw, da.hw, c_up, da.cin, 0, stream));
+    {
+      const float* pss = ws + L.ss[prev];
+      int nblk = 0;
+      RC(tdx_bilinear_ac_bwd_bn(gcat, gup, B, dp.hw, dp.hw, da.hw, da.hw, c_up, da.cin, 0, bw_y(prev), pss, pss + c_up,
+                                pss + 2 * c_up, pss + 3 * c_up, ws + L.bnscr, &nblk, stream));
+      if (nblk > 0) { u->bw_unit = prev; u->bw_nblk = nblk; }
+    }
     touch(gcat);
     g_next = gup;
     return 0;
@@ -922,8 +959,14 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     RC(acquire(gpool, nullptr, &gnew));
     // GS[k] was written on the third stream during the decoder
     TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[2 - k], 0));
-    RC(tdx_maxpool2_ceil_bwd(ws + L.Y[ub], ssc(ub), ssh(ub), gpool, ws + L.GS[k], gnew, B, S.enc_hw[k],
-                             S.enc_hw[k], S.skip_ch[k], stream));
+    {
+      const int cu = S.skip_ch[k];
+      int nblk = 0;
+      RC(tdx_maxpool2_ceil_bwd_bn(ws + L.Y[ub], ssc(ub), ssh(ub), gpool, ws + L.GS[k], gnew, B, S.enc_hw[k],
+                                  S.enc_hw[k], cu, ws + L.ss[ub] + 2 * cu, ws + L.ss[ub] + 3 * cu,
+                                  bf16 ? nullptr : ws + L.bnscr, &nblk, stream));
+      if (nblk > 0) { u->bw_unit = ub; u->bw_nblk = nblk; }
+    }
     touch(gpool);
     g_next = gnew;
     return 0;
@@ -944,7 +987,11 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
             g_next = gd1a;
           } else {
             RC(acquire(gd1a, nullptr, &g12));
-            RC(tdx_bilinear_ac_bwd(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, stream));
+            const float* pss = ws + L.ss[12];
+            int nblk = 0;
+            RC(tdx_bilinear_ac_bwd_bn(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, bw_y(12), pss,
+                                      pss + 64, pss + 128, pss + 192, ws + L.bnscr, &nblk, stream));
+            if (nblk > 0) { u->bw_unit = 12; u->bw_nblk = nblk; }
             g_next = g12;
           }
         }
