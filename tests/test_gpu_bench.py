@@ -41,3 +41,19 @@ def test_bench_single_rank_line_shape():
         assert k in res, k
     assert res["n_gpus"] == 1 and res["dtype"] == "f32" and res["vs_baseline"] is None
     assert res["parity_check"]["batch"] == 256 and res["parity_check"]["eps_rel_mse_vs_oracle"] < 1e-9
+
+
+def test_bench_two_rank_line_carries_sample_latency_and_per_rank_roofline():
+    """The N > 1 line in full (BASELINE's metric names the 1000-step sample latency at every N): each rank runs
+    its own replica chains at n = 16 / 64 - no collective in the path, MAX over ranks reported - and the
+    kernel-level roofline is taken on every rank's GPU.  (Both ranks share the one visible GPU here, so the
+    figures themselves mean nothing; the shape of the line and the absence of a hang do.)"""
+    res = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"TDX_DIST_BACKEND": "gloo"}, timeout=900)
+    assert res["n_gpus"] == 2
+    s = res["sample"]
+    assert 0 < s["n16_fastest_rank"] <= s["n16"] and 0 < s["n64_fastest_rank"] <= s["n64"]
+    assert "no collective" in s["unit"]
+    roof = res["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1
+    assert [r["rank"] for r in roof["per_rank"]] == [0, 1]
+    assert all(0 < r["frac"] < 1 for r in roof["per_rank"])

@@ -5,10 +5,13 @@
 # the default bench command.  Everything lands under gpurun_out/<tag>_*; tools/rocpd_export.py, tools/insitu.py,
 # tools/pmc_traffic.py and tools/pmc_summary.py turn it into the files kept under profiles/.
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 run() { echo "[evidence] $*" >&2; "$@"; }
+# which sources the profiled library was built from: the converters stamp it into profiles/<tag>_*.json and bench.py
+# reports a committed profile as a measurement of the running build only when the hashes agree
+python3 -c "from tiny_diffusion_amd import _build; print(_build.source_hash())" > gpurun_out/${tag}_src_sha256.txt
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_roof -- python3 bench.py --roofline-only > gpurun_out/${tag}_roof.json 2> gpurun_out/${tag}_roof.err && echo roof ok &&
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_f -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_f.err && echo pmc_f ok &&
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_w -- python3 bench.py --roofline-only > /dev/null 2> gpurun_out/${tag}_pmc_w.err && echo pmc_w ok &&

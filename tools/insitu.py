@@ -2,7 +2,7 @@
 """In-situ figures of the training step from a rocprofv3 kernel trace of
 `python3 bench.py --train-only` (the real step: three streams, kernels sharing CUs):
 
-    python tools/insitu.py <..._kernel_trace.csv> profiles/r02_insitu.json
+    python tools/insitu.py <..._kernel_trace.csv> profiles/r03_insitu.json [gpurun_out/r03_src_sha256.txt]
 
 Per step (delimited by the Adam kernel; the first two and the last step are dropped): wall time, the sum
 of the MFMA convolution kernels' durations (what `roofline.achieved` would be divided by if the
@@ -43,7 +43,8 @@ for a, b in zip(adam[2:-1], adam[3:]):
                   "conv_covered_ms": cov / 1e6, "no_conv_in_flight_ms": (t1 - t0 - cov) / 1e6,
                   "kernels": len(seg)})
 med = {k: round(statistics.median(s[k] for s in steps), 3) for k in steps[0]}
-out = {"source": sys.argv[1].split("/")[-1], "steps_used": len(steps), "median_per_step": med,
+sha = open(sys.argv[3]).read().strip() if len(sys.argv) > 3 else None   # gpurun_out/<tag>_src_sha256.txt
+out = {"src_sha256": sha, "trace": sys.argv[1].split("/")[-1], "steps_used": len(steps), "median_per_step": med,
        "in_situ_tflops": round(GFLOP_PER_STEP / med["conv_sum_ms"], 1),
        "in_situ_frac_of_157.3": round(GFLOP_PER_STEP / med["conv_sum_ms"] / PEAK, 4),
        "covered_tflops": round(GFLOP_PER_STEP / med["conv_covered_ms"], 1),

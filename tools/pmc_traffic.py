@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- python3 bench.py --roofline-only
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- python3 bench.py --roofline-only
-    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_end_pmc_hbm_traffic
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r03_pmc_hbm_traffic [gpurun_out/r03_src_sha256.txt]
 
 Units: rocprofv3 reports KB.  gfx950 correction (same guide, section HBM): FETCH_SIZE tallies the
 128-B requests of wide (16 B/lane) streaming reads - global_load and buffer_load...lds alike - as
@@ -40,7 +40,8 @@ for name, agg, n, avg in (("FETCH_SIZE", fetch, nf, f_kb), ("WRITE_SIZE", write,
 traffic_mb = (2 * f_kb + w_kb) * 1024 / 1e6
 lines.append(f"HBM traffic per conv launch (2*FETCH+WRITE): {traffic_mb:.1f} MB")
 open(sys.argv[3] + ".txt", "w").write("\n".join(lines) + "\n")
-json.dump({"traffic_mb_per_launch": round(traffic_mb, 1), "fetch_kb_reported": round(f_kb), "write_kb_reported": round(w_kb),
+sha = open(sys.argv[4]).read().strip() if len(sys.argv) > 4 else None   # gpurun_out/<tag>_src_sha256.txt
+json.dump({"src_sha256": sha, "traffic_mb_per_launch": round(traffic_mb, 1), "fetch_kb_reported": round(f_kb), "write_kb_reported": round(w_kb),
            "launches": nf, "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950, MI355X_MICROARCH.md HBM section)",
            "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --roofline-only (two passes)"},
           open(sys.argv[3] + ".json", "w"), indent=1)
