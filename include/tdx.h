@@ -484,6 +484,16 @@ int tdx_unet_eval_step(tdx_unet* u, const void* const* params, void* const* buff
                        void* workspace, size_t workspace_bytes, int batch, uint64_t philox_seed,
                        tdx_stream_t stream);
 
+/* Sampling tables (optional, a speed-up only).  The time / class signal enters the network through projections
+ * that are linear in the embedding, so inside one sample() call W_k MLP(t) + b_k is a table over t < T and
+ * W_k c_b a table over the samples: built here once (for the plan's current INFER pack - call after
+ * tdx_unet_pack - and for exactly this batch and this cond pointer, whose contents are read now), after which
+ * tdx_unet_eval_step with the same batch / cond replaces its step counter, time MLP and projection launches by one
+ * table look-up kernel (results equal up to fp32 reassociation of one sum).  May allocate: not inside a capture.
+ * Any later tdx_unet_pack invalidates the tables (eval steps then take the direct path). */
+int tdx_unet_prepare_sampling(tdx_unet* u, const void* const* params, const void* cond, int batch, int T,
+                              tdx_stream_t stream);
+
 /* Testing aid: offset (in floats) and element count of a named intermediate inside the
  * workspace after a forward: "x0", "Y0".."Y12", "ss0".."ss12", "e1p", "cat1", "d1a", ... */
 int tdx_unet_tensor(const tdx_unet* u, int batch, const char* name, size_t* offset_floats,

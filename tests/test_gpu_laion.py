@@ -479,3 +479,36 @@ def test_laion_input_gradient_matches_oracle():
         err_gpu = (xg.grad.double().cpu() - outs[torch.float64]).norm().item() / n64
         print(f"laion d/dx {hw}x{hw}: gpu {err_gpu:.2e}, cpu fp32 {err_cpu:.2e}")
         assert err_gpu <= max(10 * err_cpu, 1e-4), (hw, err_gpu, err_cpu)
+
+
+def test_laion_sampling_tables_match_direct_time_path():
+    """Table-mode reverse steps of the LAION network (time table over t, W_k text_b over the samples) against the
+    direct time path, same Philox noise (see tests/test_gpu_unet.py::test_sampling_tables_match_direct_time_path)."""
+    from tiny_diffusion_amd.conditional_diffusion_laion import ForwardProcess
+
+    m = build(3).eval()
+    n, T = 3, 25
+    fp = ForwardProcess(num_timesteps=T)
+    _, _, coef = fp.tables("cuda")
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(n, 4, 32, 32, generator=g).cuda()
+    cond = torch.randn(n, 768, generator=g).cuda()
+    outs = []
+    for tables in (False, True):
+        x = x0.clone()
+        counter = torch.full((1,), T - 1, dtype=torch.int64, device="cuda")
+        t_idx = torch.empty(1, dtype=torch.int32, device="cuda")
+        t_vec = torch.empty(n, dtype=torch.int64, device="cuda")
+        eps = torch.empty_like(x)
+        with torch.no_grad():
+            if tables:
+                m._run_eval_step(x0.clone(), cond, coef, counter.clone(), t_idx, t_vec, eps, philox_seed=5)  # pack
+                m._prepare_sampling(x, cond, T)
+            for _ in range(T):
+                m._run_eval_step(x, cond, coef, counter, t_idx, t_vec, eps, philox_seed=5)
+        torch.cuda.synchronize()
+        assert int(counter) == -1
+        outs.append(x.clone())
+    r = rel_mse(outs[1], outs[0])
+    print(f"laion table-mode vs direct chain: relative MSE {r:.2e}")
+    assert torch.isfinite(outs[1]).all() and r < 1e-10

@@ -676,3 +676,45 @@ def test_bn_backward_fused_partials_match_reduction_pass(cond, training, B):
         worst = max(worst, err)
         assert err < 2e-5, (k, err)
     print(f"fused vs reduction-pass BN backward, B={B} cond={cond} training={training}: worst rel. diff {worst:.2e}")
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_sampling_tables_match_direct_time_path(cond):
+    """Table-mode reverse steps (tdx_unet_prepare_sampling: W_k MLP(t) + b_k tabulated over t, W_k E[y] over
+    the samples; one look-up kernel per step in place of the step counter, the time MLP and the projections, the
+    counter advanced by the update kernel) against the direct path on the same Philox noise: the projections are
+    linear in the embedding (diffusion.py:130-132), so the chains agree to fp32 reassociation of one sum per
+    projection.  Also: a pack refresh invalidates the tables (the step falls back to the direct path)."""
+    from tiny_diffusion_amd._lib import lib, check
+    from tiny_diffusion_amd.diffusion import ForwardProcess
+
+    m = build(cond, 21).eval()
+    n, T = 5, 40
+    fp = ForwardProcess(num_timesteps=T)
+    _, _, coef = fp.tables("cuda")
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(n, 1, 28, 28, generator=g).cuda()
+    y = torch.randint(0, 10, (n,), generator=g).cuda() if cond else None
+    outs = []
+    for tables in (False, True, False):
+        x = x0.clone()
+        counter = torch.full((1,), T - 1, dtype=torch.int64, device="cuda")
+        t_idx = torch.empty(1, dtype=torch.int32, device="cuda")
+        t_vec = torch.empty(n, dtype=torch.int64, device="cuda")
+        eps = torch.empty_like(x)
+        with torch.no_grad():
+            if outs and not tables:   # third round: a new pack generation must switch the (now stale) tables off
+                m._buf_epoch += 1
+            m._run_eval_step(x, y, coef, counter, t_idx, t_vec, eps, philox_seed=11)   # builds the INFER pack
+            if tables:
+                m._prepare_sampling(x, y, T)
+            for _ in range(T - 1):
+                m._run_eval_step(x, y, coef, counter, t_idx, t_vec, eps, philox_seed=11)
+        torch.cuda.synchronize()
+        assert int(counter) == -1 and int(t_idx) == 0 and int(t_vec[0]) == 0
+        outs.append(x.clone())
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[2])   # direct path twice: bit-identical
+    r = rel_mse(outs[1], outs[0])
+    print(f"table-mode vs direct chain, T={T}, cond={cond}: relative MSE {r:.2e}")
+    assert r < 1e-10 and not torch.equal(outs[1], outs[0]) or r == 0.0

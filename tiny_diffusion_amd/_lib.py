@@ -145,6 +145,7 @@ _SIGS = {
                                     _ptr]),
     "tdx_unet_backward_join": (C.c_int, [_ptr, _ptr]),
     "tdx_unet_request_input_grad": (C.c_int, [_ptr, _ptr]),
+    "tdx_unet_prepare_sampling": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, _ptr]),
     "tdx_initial_conv_input_grad": (C.c_int, [_ptr, _ptr, _ptr] + [C.c_int] * 5 + [_ptr]),
     "tdx_unet_eval_step": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, C.c_int64,
                                      _ptr, C.c_size_t, C.c_int, C.c_uint64, _ptr]),

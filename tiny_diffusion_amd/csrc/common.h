@@ -60,6 +60,13 @@ __device__ static inline float4 philox_normal4(uint64_t ctr, uint64_t stream, ui
   return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
 }
 
+// x' = c1*(x - c2*eps) + sigma*z in the reference's operation order (diffusion.py:272-274): mul, sub, mul, mul, add,
+// each rounded separately
+__device__ static inline float p_step(float x, float e, float z, float c1, float c2, float sg) {
+  float inner = __fsub_rn(x, __fmul_rn(c2, e));
+  return __fadd_rn(__fmul_rn(c1, inner), __fmul_rn(sg, z));
+}
+
 __device__ static inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -580,6 +580,45 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
   }
 }
 
+// The inference reduction with the 2x2 ceil-mode max-pool that follows the unit folded in (sampling: one launch
+// fewer per encoder level): a thread owns one pooled position x 4 channels, reduces the (up to) four pixels of its
+// window in the fixed split order, writes each (the skip connection reads the unpooled tensor) and their maximum.
+__global__ void splitk_reduce_pool_kernel(const float* __restrict__ partial, int splits, size_t slab, int B, int H,
+                                          int W, int cout, const float* __restrict__ bias,
+                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                          float* __restrict__ out, float* __restrict__ pooled) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = cout / 4;
+  const int64_t n = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t p = i / c4n;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
+      if (ih < H && iw < W) {
+        const size_t off = (((size_t)b * H + ih) * W + iw) * cout + c;
+        float4 acc = bv;
+        for (int sp = 0; sp < splits; ++sp) {
+          const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)sp * slab + off);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); acc.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+        acc.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); acc.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+        *reinterpret_cast<float4*>(out + off) = acc;
+        m.x = fmaxf(m.x, acc.x); m.y = fmaxf(m.y, acc.y); m.z = fmaxf(m.z, acc.z); m.w = fmaxf(m.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(pooled + i * 4) = m;
+  }
+}
+
 // Training form of the reduction: out = bias + sum_s partial[s] (fixed order) AND the BatchNorm
 // statistics partials the convolution epilogue would have written - per tile of TILE_ROWS pixels and per
 // channel the sum and the sum of squared deviations from the TILE mean - so that bn_finalize sees the
@@ -734,6 +773,9 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "sample_fuse")) { g_tdx_sample_fuse = value & 7; return 0; }
+  if (!strcmp(key, "sample_defer_max")) { g_tdx_sample_defer_max = value; return 0; }
+  if (!strcmp(key, "sample_tables")) { g_tdx_sample_tables = value != 0; return 0; }
   if (!strcmp(key, "bnbwd_fused")) { g_tdx_bnbwd_fused = value & 7; return 0; }
   if (!strcmp(key, "conv_hybrid")) { g_conv_hybrid = value != 0; return 0; }
   if (!strcmp(key, "splitk_fused")) { g_splitk_fused = value != 0; return 0; }
@@ -989,7 +1031,8 @@ static int launch_hybrid(ConvArgs a, const HybridPlan& h, float* scratch, bool s
 
 template <int EPI_>
 static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scratch, hipStream_t st,
-                         unsigned* counters = nullptr, int n_counters = 0) {
+                         unsigned* counters = nullptr, int n_counters = 0, TdxSplitDefer* defer = nullptr,
+                         float* pool_out = nullptr, bool* pooled = nullptr) {
   float* final_out = a.out;
   a.out = scratch;
   a.splits = splits;
@@ -1011,6 +1054,20 @@ static int launch_splitk(ConvArgs a, bool in_bn, int splits, int per, float* scr
     conv3x3_igemm_dma_kernel<64, 64, EPI_PLAIN, true><<<grid, 256, (size_t)2 * 128 * BK * sizeof(float), st>>>(a);
   else conv3x3_igemm2_kernel<64, 64, false, EPI_PLAIN, true><<<grid, 256, lds, st>>>(a);
   TDX_CHECK_LAUNCH();
+  if (EPI_ == EPI_BNRELU && defer && splits <= g_tdx_sample_defer_max) {   // the consumer of this tensor reduces on load (spatial.hip, ResizeSrc)
+    *defer = TdxSplitDefer{scratch, splits, (size_t)a.M * a.Cout, a.bias, a.out_scale, a.out_shift};
+    return 0;
+  }
+  if (EPI_ == EPI_BNRELU && pool_out) {
+    const int64_t np = (int64_t)a.B * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
+    int pg = (int)((np + 255) / 256);
+    if (pg > 2048) pg = 2048;
+    splitk_reduce_pool_kernel<<<pg, 256, 0, st>>>(scratch, splits, (size_t)a.M * a.Cout, a.B, a.H, a.W, a.Cout, a.bias,
+                                                  a.out_scale, a.out_shift, final_out, pool_out);
+    TDX_CHECK_LAUNCH();
+    if (pooled) *pooled = true;
+    return 0;
+  }
   const int64_t n4 = (int64_t)a.M * a.Cout / 4;
   int rg = (int)((n4 + 255) / 256);
   if (rg > 2048) rg = 2048;
@@ -1052,6 +1109,11 @@ extern "C" int tdx_conv3x3_shape_ok(int B, int H, int W, int cin, int cout) {
 // extra operands of the EPI_BNBWD epilogue (set by tdx_conv3x3_dgrad_bnbwd around its call; host-side only)
 struct BwOperands { const float *y, *scale, *shift, *mean, *rstd; float* partial; };
 static thread_local BwOperands g_bw = {};
+// sampling-only extras of tdx_conv3x3_fwd_splitk_fused, set around its call: defer the split-K reduction to the
+// consumer / fold the following max-pool into it (internal.h)
+static thread_local TdxSplitDefer* g_defer = nullptr;
+static thread_local float* g_pool_out = nullptr;
+static thread_local bool g_pool_done = false;
 
 static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias, float* out,
                             int B, int H, int W, int cin, int cout, int flags,
@@ -1117,7 +1179,8 @@ static int conv3x3_fwd_impl(const float* in, const float* wpk, const float* bias
     if (splits > 1) {
       const bool in_bn = flags & TDX_CONV_IN_BNRELU;
       if (flags & TDX_CONV_OUT_BNRELU)
-        return launch_splitk<EPI_BNRELU>(a, in_bn, splits, per, splitk_scratch, st, counters, n_counters);
+        return launch_splitk<EPI_BNRELU>(a, in_bn, splits, per, splitk_scratch, st, counters, n_counters, g_defer,
+                                         g_pool_out, &g_pool_done);
       return launch_splitk<EPI_PLAIN>(a, in_bn, splits, per, splitk_scratch, st, counters, n_counters);
     }
   }
@@ -1140,10 +1203,19 @@ extern "C" int tdx_conv3x3_fwd(const float* in, const float* wpk, const float* b
 int tdx_conv3x3_fwd_splitk_fused(const float* in, const float* wpk, const float* bias, float* out, int B, int H,
                                  int W, int cin, int cout, int flags, const float* out_scale,
                                  const float* out_shift, float* scratch, size_t scratch_floats, unsigned* counters,
-                                 int n_counters, tdx_stream_t stream) {
+                                 int n_counters, tdx_stream_t stream, TdxSplitDefer* defer, TdxPoolFuse* pool) {
   if (!scratch) return TDX_E_BADARG;
-  return conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, nullptr, nullptr, out_scale, out_shift,
-                          nullptr, scratch, scratch_floats, stream, false, counters, n_counters);
+  if (defer) *defer = TdxSplitDefer{};
+  g_defer = defer;
+  g_pool_out = pool ? pool->pooled : nullptr;
+  g_pool_done = false;
+  if (g_splitk_fused) g_defer = nullptr, g_pool_out = nullptr;   // (the in-kernel reduction experiment owns the epilogue)
+  const int rc = conv3x3_fwd_impl(in, wpk, bias, out, B, H, W, cin, cout, flags, nullptr, nullptr, out_scale, out_shift,
+                                  nullptr, scratch, scratch_floats, stream, false, counters, n_counters);
+  if (pool && !g_pool_done) pool->pooled = nullptr;   // not split: the caller runs the pooling kernel
+  g_defer = nullptr;
+  g_pool_out = nullptr;
+  return rc;
 }
 
 extern "C" int tdx_conv3x3_fwd_train(const float* in, const float* wpk, const float* bias, float* out, int B,

@@ -119,10 +119,18 @@ thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict_
 // sum_{o,tap} g(x0)[p - tap][o] W[o][c][tap] = sum_{tap'} sum_o g(x0)[p + tap'][o] W[o][c][8 - tap'], i.e. this
 // kernel on the gradient of x0 with the weight image ws[c][tap'][o] = initial_conv.weight[o][c][8 - tap'] (w is
 // [cor][CO][9]; stored channels o >= cor are padding: zero weights) and no bias.
-template <int CO, bool DGRAD = false>
+// PS = true (sampling): the reverse-process update of diffusion.py:272-274 in the epilogue - the lane that holds
+// eps_hat of an element also reads x, draws or loads z and writes x' in place (x is not an input of this kernel:
+// the network read it in initial_conv), exactly the arithmetic and the Philox indexing of p_sample_kernel; the
+// step's last launch disappears.  eps_hat is still written to `out`.
+struct PSampleOps {
+  float* x; const float* z; const float* coef; const int32_t* t_idx; uint64_t seed; int philox; int64_t* counter_dec;
+};
+template <int CO, bool DGRAD = false, bool PS = false>
 __global__ void __launch_bounds__(256)
 fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int cor = IC_CO) {
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int cor = IC_CO,
+                        PSampleOps ps = PSampleOps{}) {
   __shared__ __attribute__((aligned(16))) float ws[CO][9][IC_CO];
   if (DGRAD) {
     for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {
@@ -143,6 +151,14 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
   float bv[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) bv[co] = DGRAD ? 0.f : bias[co];
+  int ps_t = 0;
+  float ps_c1 = 0.f, ps_c2 = 0.f, ps_sg = 0.f;
+  if (PS) {
+    ps_t = *ps.t_idx;
+    ps_c1 = ps.coef[3 * ps_t + 0]; ps_c2 = ps.coef[3 * ps_t + 1]; ps_sg = ps.coef[3 * ps_t + 2];
+    // table-mode sampling: the step counter is advanced by the last kernel of the step (see p_sample_kernel)
+    if (ps.counter_dec && blockIdx.x == 0 && threadIdx.x == 0) *ps.counter_dec = (int64_t)ps_t - 1;
+  }
   for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < Mpad; p += (int64_t)gridDim.x * 16) {
     float s[CO];
 #pragma unroll
@@ -178,7 +194,24 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
     }
     if ((threadIdx.x & 15) == 0 && p < M) {
 #pragma unroll
-      for (int co = 0; co < CO; ++co) out[((int64_t)n * CO + co) * HW + r] = s[co] + bv[co];
+      for (int co = 0; co < CO; ++co) {
+        const int64_t idx = ((int64_t)n * CO + co) * HW + r;
+        const float e = s[co] + bv[co];
+        out[idx] = e;
+        if (PS) {
+          float zv = 0.f;   // diffusion.py:267-270: no noise on the last step
+          if (ps_t > 0) {
+            if (ps.philox) {   // element idx = component idx % 4 of block idx / 4 (p_sample_kernel<true>)
+              const float4 z4 = philox_normal4((uint64_t)(idx >> 2), (uint64_t)ps_t, ps.seed);
+              const int k = (int)(idx & 3);
+              zv = k == 0 ? z4.x : k == 1 ? z4.y : k == 2 ? z4.z : z4.w;
+            } else if (ps.z) {
+              zv = ps.z[idx];
+            }
+          }
+          ps.x[idx] = p_step(ps.x[idx], e, zv, ps_c1, ps_c2, ps_sg);
+        }
+      }
     }
   }
 }
@@ -433,6 +466,21 @@ int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B,
   const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
   if (cin == 1 && cout_real == 64) fat_to_thin_conv_kernel<1, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
   else if (cin == 4 && cout_real == 32) fat_to_thin_conv_kernel<4, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
+  else return TDX_E_SHAPE;
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// final_conv forward with the reverse-process update fused in (sampling; PSampleOps above)
+int tdx_final_conv_fwd_psample(const float* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
+                               int cout, float* x, const float* z, const float* coef, const int32_t* t_idx,
+                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st) {
+  if (!x || !coef || !t_idx) return TDX_E_BADARG;
+  const int64_t M = (int64_t)B * H * W;
+  const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
+  const PSampleOps ps{x, z, coef, t_idx, seed, philox, counter_dec};
+  if (cout == 1) fat_to_thin_conv_kernel<1, false, true><<<grid, 256, 0, st>>>(in, w, bias, eps_out, B, H, W, IC_CO, ps);
+  else if (cout == 4) fat_to_thin_conv_kernel<4, false, true><<<grid, 256, 0, st>>>(in, w, bias, eps_out, B, H, W, IC_CO, ps);
   else return TDX_E_SHAPE;
   TDX_CHECK_LAUNCH();
   return 0;

@@ -84,17 +84,17 @@ extern "C" int tdx_q_sample_philox(const float* x0, const int64_t* t, const floa
 // ------------------------------------------------------------- p_sample step
 // x' = c1*(x - c2*eps) + sigma*z, evaluated in the reference's operation order
 // (diffusion.py:272-274): mul, sub, mul, mul, add - each rounded separately.
-__device__ static inline float p_step(float x, float e, float z, float c1, float c2, float sg) {
-  float inner = __fsub_rn(x, __fmul_rn(c2, e));
-  return __fadd_rn(__fmul_rn(c1, inner), __fmul_rn(sg, z));
-}
+// (p_step: common.h - the boundary convolution fuses the same update into its epilogue when sampling)
 
 template <bool PHILOX>
 __global__ void p_sample_kernel(float4* xo, const float4* x,  // may alias: in-place update
                                 const float4* __restrict__ eps, const float4* __restrict__ z,
                                 const float* __restrict__ coef, const int32_t* __restrict__ t_idx,
-                                int64_t n4, uint64_t seed) {
+                                int64_t n4, uint64_t seed, int64_t* counter_dec = nullptr) {
   const int t = *t_idx;
+  // table-mode sampling (tdx_unet_eval_step): the step counter is advanced HERE, by the last kernel of the
+  // step, because the head kernel of the step reads it from every workgroup (nobody else touches it in between)
+  if (counter_dec && blockIdx.x == 0 && threadIdx.x == 0) *counter_dec = (int64_t)t - 1;
   const float c1 = coef[3 * t + 0], c2 = coef[3 * t + 1], sg = coef[3 * t + 2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -120,6 +120,21 @@ extern "C" int tdx_p_sample_step(float* x_out, const float* x, const float* eps,
   p_sample_kernel<false><<<ew_grid(n / 4, 256), 256, 0, to_stream(stream)>>>(
       (float4*)x_out, (const float4*)x, (const float4*)eps, (const float4*)z, coef, t_idx, n / 4,
       0);
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
+// the update with the counter decrement of table-mode sampling folded in (z == null: in-kernel Philox noise)
+int tdx_p_sample_step_dec(float* x_out, const float* x, const float* eps, const float* z, const float* coef,
+                          const int32_t* t_idx, int64_t n, uint64_t seed, int64_t* counter_dec, hipStream_t st) {
+  if (!x_out || !x || !eps || !coef || !t_idx || n <= 0) return TDX_E_BADARG;
+  if (n % 4) return TDX_E_SHAPE;
+  if (z)
+    p_sample_kernel<false><<<ew_grid(n / 4, 256), 256, 0, st>>>((float4*)x_out, (const float4*)x, (const float4*)eps,
+                                                               (const float4*)z, coef, t_idx, n / 4, 0, counter_dec);
+  else
+    p_sample_kernel<true><<<ew_grid(n / 4, 256), 256, 0, st>>>((float4*)x_out, (const float4*)x, (const float4*)eps,
+                                                              nullptr, coef, t_idx, n / 4, seed, counter_dec);
   TDX_CHECK_LAUNCH();
   return 0;
 }

@@ -18,6 +18,9 @@ int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B,
                            int cout_real, hipStream_t st);
 int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
                        int W, int cout, hipStream_t st);
+int tdx_final_conv_fwd_psample(const float* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
+                               int cout, float* x, const float* z, const float* coef, const int32_t* t_idx,
+                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st);
 int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
                          int cout, hipStream_t st);
 int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
@@ -37,10 +40,13 @@ enum { TDX_TIME_PROJ = 1, TDX_TIME_MID = 2, TDX_TIME_L1 = 4 };
 // one projection's share of TDX_TIME_PROJ (time_embed.hip)
 int tdx_time_proj_bwd(int kind, int k, const float* const* P, float* const* G, const float* emb,
                       const float* g_tk, float* scratch, int B, hipStream_t st, int td = 0);
+struct TdxSplitDefer;
+struct TdxPoolFuse;
 int tdx_conv3x3_fwd_splitk_fused(const float* in, const float* wpk, const float* bias, float* out, int B, int H,
                                  int W, int cin, int cout, int flags, const float* out_scale,
                                  const float* out_shift, float* scratch, size_t scratch_floats, unsigned* counters,
-                                 int n_counters, tdx_stream_t stream);
+                                 int n_counters, tdx_stream_t stream, TdxSplitDefer* defer = nullptr,
+                                 TdxPoolFuse* pool = nullptr);
 #define TDX_PACK_MAX 13
 struct TdxPackBatch {
   const float* w[TDX_PACK_MAX];
@@ -75,6 +81,16 @@ extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd
 extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
                         float* tf_out, int B, hipStream_t st);
+// sampling tables (time_embed.hip) and the pieces of a table-mode reverse step
+int tdx_time_tables_build(int kind, const float* const* P, int T, int td, float* tab1, float* tab2, float* tab3,
+                          float* scratch, hipStream_t st);
+int tdx_time_tables_cond(int kind, const float* const* P, const void* cond, int B, int td, float* tabc1, float* tabc2,
+                         float* tabc3, float* scratch, hipStream_t st);
+int tdx_sample_head(const int64_t* counter, int32_t* t_idx, int64_t* t_vec, int B, int T, int kind, const float* tab1,
+                    const float* tab2, const float* tab3, const float* tc1, const float* tc2, const float* tc3,
+                    float* o1, float* o2, float* o3, hipStream_t st);
+int tdx_p_sample_step_dec(float* x_out, const float* x, const float* eps, const float* z, const float* coef,
+                          const int32_t* t_idx, int64_t n, uint64_t seed, int64_t* counter_dec, hipStream_t st);
 // latent MLP noise model (latent_diffusion.py:16-128), kind TDX_UNET_LATENT_MLP of tdx_unet_*
 size_t tdx_latent_workspace_floats(int B);
 size_t tdx_latent_infer_ss_floats(void);
@@ -98,6 +114,9 @@ extern int g_tdx_time_stage;
 // convolution of the unit above, the resize adjoint or the max-pool backward) also emits the partial sums of that
 // unit's BatchNorm backward, and the separate reduction pass is skipped (unet.hip, tdx_unet_backward)
 extern int g_tdx_bnbwd_fused;
+extern int g_tdx_sample_tables;
+extern int g_tdx_sample_fuse;       // bit 0 defer split-K reductions into the resize kernels, 1 pool in the reduction, 2 update in final_conv
+extern int g_tdx_sample_defer_max;
 int tdx_conv3x3_dgrad_bnbwd(const float* in, const float* wpk, float* out, int B, int H, int W, int cin, int cout,
                             const float* y, const float* scale, const float* shift, const float* mean,
                             const float* rstd, float* partial, int* nblk, float* scratch, size_t scratch_floats,
@@ -120,5 +139,18 @@ int tdx_maxpool2_ceil_bwd_bn(const float* y, const float* scale, const float* sh
 #define TDX_BNBWD_MAX_PRODUCER_BLOCKS 2048   // workgroups of the two spatial producers above
 extern int g_tdx_time_proj_early;
 // inference: both halves of a decoder's concatenated input (resize(a) | resize(b + b_addend)) in one launch
+// A split-K convolution of the sampling path whose reduction is DEFERRED to the kernel that reads its result
+// (tdx_conv3x3_fwd_splitk_fused with a non-null `defer`): `splits` raw partial slabs of `slab` floats at `partial`,
+// to be summed in the order 0..splits-1, + bias, then relu(. * scale + shift).  splits == 0: the convolution was not
+// split (or not deferrable) and wrote its output tensor as usual.
+// the 2x2 ceil-mode max-pool that follows a sampling convolution, done by its split-K reduction (pooled = null on
+// return when the convolution was not split: the caller then runs the pooling kernel)
+struct TdxPoolFuse { float* pooled; };
+struct TdxSplitDefer {
+  const float* partial; int splits; size_t slab; const float* bias; const float* scale; const float* shift;
+};
+int tdx_bilinear_pair_fwd_ex(const float* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const float* b,
+                             const float* b_addend, int Hb, int Wb, int Cb, float* out, int B, int Ho, int Wo,
+                             hipStream_t st);
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
                           int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st);

@@ -259,8 +259,14 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* _
 
 // Both halves of a decoder input in ONE launch (inference / sampling, where every launch is ~5 us
 // of a ~550 us step): channels [0, CA) = resize(A), channels [CA, CA+CB) = resize(Bsrc + addend).
+// A source may be a DEFERRED split-K result (sampling: TdxSplitDefer, internal.h): `in` then points at `splits` raw
+// partial slabs of `slab` floats and the loader forms relu((bias + sum_s partial_s) * scale + shift) itself, in
+// the fixed order 0..splits-1 - the separate reduction launch of that convolution (and the tensor it would have
+// written, which nothing else reads in INFER mode) disappears.  An up-sampled source is touched by ~4 outputs
+// per element, so the sums are formed ~4 times over; the partials of a 16-sample step are L2-resident.
 struct ResizeSrc {
   const float* in; const float* addend; int Hi, Wi, C; float sch, scw;
+  int splits; size_t slab; const float* bias; const float* scale; const float* shift;
 };
 __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __restrict__ out, int B, int Ho,
                                          int Wo) {
@@ -280,8 +286,25 @@ __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __res
     float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
     if (S.addend) ad = *reinterpret_cast<const float4*>(S.addend + (int64_t)b * S.C + c);
     const float* base = S.in + (int64_t)b * S.Hi * S.Wi * S.C + c;
+    float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f), dsc = dbv, dsh = dbv;
+    if (S.splits > 0) {
+      if (S.bias) dbv = *reinterpret_cast<const float4*>(S.bias + c);
+      dsc = *reinterpret_cast<const float4*>(S.scale + c);
+      dsh = *reinterpret_cast<const float4*>(S.shift + c);
+    }
     auto ld = [&](int h, int w) {
-      float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)h * S.Wi + w) * S.C);
+      const float* q = base + ((int64_t)h * S.Wi + w) * S.C;
+      float4 v;
+      if (S.splits > 0) {   // deferred split-K source: the reduction epilogue of splitk_reduce_kernel<true>, on load
+        v = dbv;
+        for (int sp = 0; sp < S.splits; ++sp) {
+          const float4 t = *reinterpret_cast<const float4*>(q + (size_t)sp * S.slab);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v = bnrelu4(v, dsc, dsh);
+      } else {
+        v = *reinterpret_cast<const float4*>(q);
+      }
       v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
       return v;
     };
@@ -324,9 +347,22 @@ extern "C" int tdx_bilinear_ac_fwd(const float* in, const float* scale, const fl
 
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
                           int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st) {
-  if (!a || !b || !out || Ca % 4 || Cb % 4) return TDX_E_BADARG;
-  ResizeSrc A{a, nullptr, Ha, Wa, Ca, ac_scale(Ha, Ho), ac_scale(Wa, Wo)};
-  ResizeSrc Bs{b, b_addend, Hb, Wb, Cb, ac_scale(Hb, Ho), ac_scale(Wb, Wo)};
+  return tdx_bilinear_pair_fwd_ex(a, nullptr, Ha, Wa, Ca, b, b_addend, Hb, Wb, Cb, out, B, Ho, Wo, st);
+}
+
+// the same with source A optionally a deferred split-K result (a_defer != null: `a` is ignored) and source B optional
+// (Cb == 0: a plain resize of A into `out`)
+int tdx_bilinear_pair_fwd_ex(const float* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const float* b,
+                             const float* b_addend, int Hb, int Wb, int Cb, float* out, int B, int Ho, int Wo,
+                             hipStream_t st) {
+  const bool deferred = a_defer && a_defer->splits > 0;
+  if ((!a && !deferred) || (!b && Cb) || !out || Ca % 4 || Cb % 4 || Ca <= 0 || Cb < 0) return TDX_E_BADARG;
+  if (deferred && (!a_defer->partial || !a_defer->scale || !a_defer->shift)) return TDX_E_BADARG;
+  ResizeSrc A{deferred ? a_defer->partial : a, nullptr, Ha, Wa, Ca, ac_scale(Ha, Ho), ac_scale(Wa, Wo),
+              deferred ? a_defer->splits : 0, deferred ? a_defer->slab : 0, deferred ? a_defer->bias : nullptr,
+              deferred ? a_defer->scale : nullptr, deferred ? a_defer->shift : nullptr};
+  ResizeSrc Bs{b, b_addend, Cb ? Hb : 1, Cb ? Wb : 1, Cb, Cb ? ac_scale(Hb, Ho) : 0.f, Cb ? ac_scale(Wb, Wo) : 0.f,
+               0, 0, nullptr, nullptr, nullptr};
   const int64_t n = (int64_t)B * Ho * Wo * ((Ca + Cb) / 4);
   bilinear_pair_fwd_kernel<<<ew_grid(n), 256, 0, st>>>(A, Bs, out, B, Ho, Wo);
   TDX_CHECK_LAUNCH();

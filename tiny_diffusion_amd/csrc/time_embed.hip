@@ -166,7 +166,7 @@ linear_rows_kernel(const float* __restrict__ in, const float* __restrict__ w,
     if (lane < 4 * NB) {
       const int s = lane >> 2, k = lane & 3, n = n0 + s;
       if (n < B) {
-        float e = res + b[o + k];
+        float e = b ? res + b[o + k] : res;   // b == null: the bias-free product (sampling tables)
         if (addend) e += addend[(size_t)n * O + o + k];
         out[(size_t)n * O + o + k] = e;
       }
@@ -189,7 +189,7 @@ __global__ void linear_generic_kernel(const float* __restrict__ in, const float*
   const float* wr = w + (size_t)o * J;
   float s = 0.f;
   for (int j = 0; j < J; ++j) s = fmaf(wr[j], IN_SILU ? silu_f(x[j]) : x[j], s);
-  s += b[o];
+  if (b) s += b[o];
   if (addend) s += addend[idx];
   out[idx] = s;
 }
@@ -627,6 +627,100 @@ int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* 
 __global__ void t_to_float_kernel(const int64_t* __restrict__ t, float* __restrict__ tf, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) tf[i] = (float)t[i];
+}
+
+// ------------------------------------------------------------------ sampling tables
+// The time / class signal enters the network only through the three projections time_proj_k(emb) (diffusion.py:
+// 130-132), which are LINEAR in emb = MLP(t) [+ E[y] | + text]: time_proj_k(emb) = (W_k MLP(t) + b_k) + W_k c.
+// Inside sample() the weights are frozen, every sample of a step shares t and the conditioning does not change
+// from step to step, so the first term is a table over t = 0..T-1 and the second a table over the samples, both
+// built ONCE per sample() call; a reverse step then adds two rows per sample instead of running the MLP and the
+// projections (two launches of the 37 of a step at n = 16, where a launch boundary costs as much as a small
+// kernel).  Exact up to fp32 reassociation of that one sum ("legitimate algebraic shortcuts").
+__global__ void iota_i64_kernel(int64_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
+// tab_t{1,2,3}[t][:] = W_k MLP(t) + b_k for t < T.  scratch: 2*T floats (the int64 step indices) + 3*T*td.
+int tdx_time_tables_build(int kind, const float* const* P, int T, int td, float* tab1, float* tab2, float* tab3,
+                          float* scratch, hipStream_t st) {
+  if (td <= 0) td = kind == 1 ? TDL : TD;
+  int64_t* tt = reinterpret_cast<int64_t*>(scratch);
+  float* sin = scratch + 2 * (size_t)T;
+  float* pre = sin + (size_t)T * td;
+  float* emb = pre + (size_t)T * td;
+  iota_i64_kernel<<<cdiv(T, 256), 256, 0, st>>>(tt, T);
+  TDX_CHECK_LAUNCH();
+  return tdx_time_embed_fwd(kind, tt, nullptr, nullptr, P, sin, pre, emb, tab1, tab2, tab3, T, st, td);
+}
+
+// e_c[b][:] = E[y[b]][:]  (kind 0, class-conditional)
+__global__ void class_rows_kernel(const float* __restrict__ cls, const int64_t* __restrict__ y, float* __restrict__ out,
+                                  int B, int td) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * td) return;
+  const int n = i / td, j = i - n * td;
+  out[i] = cls[(size_t)y[n] * td + j];
+}
+
+// tabc{1,2,3}[b][:] = W_k c_b (no bias), c_b = E[y_b] (kind 0, labels) or the text embedding of sample b (kind 1).
+// scratch: B*td floats (kind 0).
+int tdx_time_tables_cond(int kind, const float* const* P, const void* cond, int B, int td, float* tabc1, float* tabc2,
+                         float* tabc3, float* scratch, hipStream_t st) {
+  if (td <= 0) td = kind == 1 ? TDL : TD;
+  const float* c = static_cast<const float*>(cond);
+  if (kind == 0) {
+    class_rows_kernel<<<cdiv((int64_t)B * td, 256), 256, 0, st>>>(P[TDX_P_CLASS_EMB], static_cast<const int64_t*>(cond),
+                                                                  scratch, B, td);
+    TDX_CHECK_LAUNCH();
+    c = scratch;
+  }
+  float* dst[3] = {tabc1, tabc2, tabc3};
+  const int pw[3] = {TDX_P_TP1_W, TDX_P_TP2_W, TDX_P_TP3_W};
+  for (int k = 0; k < 3; ++k) {
+    const int width = (kind == 1 ? 64 : 128) << k;
+    const int rc = linear_rows<false>(c, P[pw[k]], nullptr, nullptr, dst[k], B, width, td, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// Head of a reverse step in table mode: t = *counter (read only: the decrement moved to the END of the step, into
+// the update kernel, so that every workgroup here sees the same value); t_idx = t; t_vec[:] = t;
+// tp_k[b][:] = tab_tk[t][:] + tabc_k[b][:].  One launch in place of step_begin + the time MLP + the projections.
+__global__ void __launch_bounds__(256)
+sample_head_kernel(const int64_t* __restrict__ counter, int32_t* __restrict__ t_idx, int64_t* __restrict__ t_vec,
+                   int B, int T, int w1, int w2, int w3, const float* __restrict__ tab1,
+                   const float* __restrict__ tab2, const float* __restrict__ tab3, const float* __restrict__ tc1,
+                   const float* __restrict__ tc2, const float* __restrict__ tc3, float* __restrict__ o1,
+                   float* __restrict__ o2, float* __restrict__ o3) {
+  const int64_t t64 = *counter;
+  const int t = (int)(t64 < 0 ? 0 : t64 >= T ? T - 1 : t64);   // the tables hold T rows
+  const int wsum = w1 + w2 + w3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) t_vec[i] = t64;
+  if (i == 0) *t_idx = (int32_t)t64;
+  if (i >= B * wsum) return;
+  const int b = i / wsum, j = i - b * wsum;
+  if (j < w1) o1[b * w1 + j] = tab1[(size_t)t * w1 + j] + (tc1 ? tc1[b * w1 + j] : 0.f);
+  else if (j < w1 + w2) {
+    const int q = j - w1;
+    o2[b * w2 + q] = tab2[(size_t)t * w2 + q] + (tc2 ? tc2[b * w2 + q] : 0.f);
+  } else {
+    const int q = j - w1 - w2;
+    o3[b * w3 + q] = tab3[(size_t)t * w3 + q] + (tc3 ? tc3[b * w3 + q] : 0.f);
+  }
+}
+
+int tdx_sample_head(const int64_t* counter, int32_t* t_idx, int64_t* t_vec, int B, int T, int kind, const float* tab1,
+                    const float* tab2, const float* tab3, const float* tc1, const float* tc2, const float* tc3,
+                    float* o1, float* o2, float* o3, hipStream_t st) {
+  const int w1 = kind == 1 ? 64 : 128, w2 = 2 * w1, w3 = 4 * w1;
+  sample_head_kernel<<<cdiv((int64_t)B * (w1 + w2 + w3), 256), 256, 0, st>>>(counter, t_idx, t_vec, B, T, w1, w2, w3,
+                                                                              tab1, tab2, tab3, tc1, tc2, tc3, o1, o2, o3);
+  TDX_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------ C ABI (the path on its own)

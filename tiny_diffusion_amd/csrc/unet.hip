@@ -164,6 +164,17 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+// Sampling (INFER forward) launch fusions, knob "sample_fuse": bit 0 a split-K result consumed only by a resize is left
+// unreduced and summed by that resize on load (splits <= "sample_defer_max"), bit 1 the reduction of units 3 / 5 also
+// does the max-pool that follows, bit 2 final_conv applies the reverse-process update in its epilogue.  Measured at
+// n = 16 (tools/gpu_ab.py, ms per reverse step, tables on): none 0.565, pool 0.564, update 0.561, both 0.562, + deferral
+// of 2-way splits 0.561, of <= 4-way 0.571, of <= 8-way 0.575.  A launch removed this way gives back 1-4 us, not the
+// 5-6 us the trace shows per small kernel: that time is the dependent pass itself (partials written behind eight L2s
+// are read back through the fabric), which the fused kernel still makes - and the deferred form re-reads every
+// partial ~4 times.  Pool and update fusion stay on (neutral to -4 us, two launches fewer); deferral is off.
+int g_tdx_sample_defer_max = 2;
+int g_tdx_sample_fuse = 6;
+int g_tdx_sample_tables = 1;    // knob "sample_tables": tdx_unet_prepare_sampling builds the tables (0: leaves eval steps on the direct path)
 int g_tdx_bnbwd_fused = 6;     // knob "bnbwd_fused" (internal.h): bit 0 input-gradient convolutions, bit 1 resize adjoints, bit 2 max-pool backward.
                                // Measured at B = 256 (tools/gpu_ab.py, ms/step): 0: 15.54, 1: 15.73, 2: 15.52, 4: 15.55, 6: 15.53, 7: 15.66 - the
                                // heavier convolution epilogue costs the GEMMs more than the reduction pass it saves (that pass is HBM-bound and
@@ -184,6 +195,16 @@ struct tdx_unet {
   unsigned* kcount;        // device: TDX_KCOUNT zeroed tile counters of the fused split-K reduction (INFER mode)
   size_t iss_off[13];
   bool packed;
+  // sampling tables (tdx_unet_prepare_sampling; time_embed.hip): tab = [T][w1] | [T][w2] | [T][w3] | cond part
+  // [tab_batch][w1|w2|w3] | scratch.  Valid for the INFER pack generation they were built at and for the
+  // (batch, cond pointer) they were built with; tdx_unet_eval_step falls back to the direct path otherwise.
+  float* tab;
+  size_t tab_floats;
+  int tab_T, tab_batch, tab_gen, pack_gen;
+  const void* tab_cond;
+  bool skip_time_path;   // set by tdx_unet_eval_step around its forward: the projections are already in the workspace
+  // set by tdx_unet_eval_step around its forward: final_conv applies the reverse-process update in its epilogue
+  struct { float* x; const float* z; const float* coef; const int32_t* t_idx; uint64_t seed; int philox; int64_t* counter_dec; } ps;
   int precision, saved_precision;  // TDX_PREC_*: of the next forward / of the saved forward
   tdx_allreduce_fn bn_sync;        // synchronised BatchNorm: all-reduce callback (null: rank-local statistics)
   void* bn_sync_user;
@@ -263,6 +284,14 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   if (e == hipSuccess) e = hipMemset(u->kcount, 0, TDX_KCOUNT * sizeof(unsigned));
   if (e != hipSuccess) { (void)hipFree(u->wpack); (void)hipFree(u->infer_ss); (void)hipFree(u->kcount); delete u; return (int)e; }
   u->packed = false;
+  u->tab = nullptr;
+  u->tab_floats = 0;
+  u->tab_T = u->tab_batch = 0;
+  u->tab_gen = -1;
+  u->pack_gen = 0;
+  u->tab_cond = nullptr;
+  u->skip_time_path = false;
+  u->ps = {};
   u->precision = TDX_PREC_F32;
   u->saved_precision = TDX_PREC_F32;
   u->bn_sync = nullptr;
@@ -363,6 +392,7 @@ extern "C" int tdx_unet_destroy(tdx_unet* u) {
   (void)hipFree(u->wpack);
   (void)hipFree(u->infer_ss);
   (void)hipFree(u->kcount);
+  if (u->tab) (void)hipFree(u->tab);
   delete u;
   return 0;
 }
@@ -439,6 +469,7 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
       if (rc) return rc;
     }
     u->packed = buffers != nullptr;
+    ++u->pack_gen;
     return 0;
   }
   TdxPackBatch pb;
@@ -476,6 +507,7 @@ static int pack_impl(tdx_unet* u, const void* const* params, void* const* buffer
     }
   }
   u->packed = buffers != nullptr;
+  ++u->pack_gen;   // sampling tables built for an earlier pack are stale
   return 0;
 }
 
@@ -575,8 +607,9 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_fork, 0));
     tst = u->side2;
   }
-  RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],
-                        ws + L.tp[1], ws + L.tp[2], B, tst, S.time_dim));
+  if (!(infer && u->skip_time_path))   // table-mode sampling: the step's head kernel has written tp[0..2] already
+    RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],
+                          ws + L.tp[1], ws + L.tp[2], B, tst, S.time_dim));
   RC(tdx_initial_conv_fwd(x, P[TDX_P_INIT_W], P[TDX_P_INIT_B], ws + L.x0, B, S.hw0, S.hw0, S.in_ch,
                           S.x0_real, st));
 
@@ -602,7 +635,10 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
                            training ? 1 : 0, stream);
   };
 
-  auto run_unit = [&](int i, const float* in) -> int {
+  // INFER (sampling) extras of a unit: `defer` = leave a split-K result unreduced for the resize kernel that reads it
+  // (units 6, 8, 10, 12: nothing else reads their output), `pool` = let the reduction do the max-pool that follows
+  // (units 3, 5 at small batches) - one launch less each, ~5 us of a ~550 us step (TdxSplitDefer / TdxPoolFuse)
+  auto run_unit = [&](int i, const float* in, TdxSplitDefer* defer = nullptr, TdxPoolFuse* pool = nullptr) -> int {
     const UnitDef& d = S.units[i];
     const float* wf = u->wpack + u->wf_off[i];
     const float* bias = P[TDX_P_UNIT0 + 4 * i + 1];
@@ -629,7 +665,8 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       // small-batch sampling is latency-bound: split K over more workgroups where the tile
       // grid would not fill the chip; the (unused in INFER mode) gradient buffers are the scratch
       return tdx_conv3x3_fwd_splitk_fused(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, iss,
-                                          iss + d.cout, ws + L.G1, 2 * L.gbuf, u->kcount, TDX_KCOUNT, stream);
+                                          iss + d.cout, ws + L.G1, 2 * L.gbuf, u->kcount, TDX_KCOUNT, stream, defer,
+                                          pool);
     }
     const bool bn_on_load = d.in_bn && !u->materialize;
     if (d.in_bn && u->materialize) in = ws + L.A[i - 1];
@@ -654,7 +691,8 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const int ua = 2 * k, ub = 2 * k + 1;
     if (k == 1 && !infer) TDX_HIP(hipStreamWaitEvent(st, u->ev_pack, 0));  // packs of units 2..12
     if (k > 0) RC(run_unit(ua, ws + L.ep[k - 1]));
-    RC(run_unit(ub, ws + L.Y[ua]));
+    TdxPoolFuse pf{infer && !bf16 && (g_tdx_sample_fuse & 2) ? ws + L.ep[k] : nullptr};
+    RC(run_unit(ub, ws + L.Y[ua], nullptr, pf.pooled ? &pf : nullptr));
     if (!infer) {
       // the skip branch resize(e_k + t_k) -> second half of the decoder's concat buffer only needs
       // this unit: do it now on the third stream, beside the rest of the encoder
@@ -668,10 +706,13 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
                              reinterpret_cast<tdx_stream_t>(u->side2)));
       TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
     }
-    RC(tdx_maxpool2_ceil_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
-                             S.skip_ch[k], stream));
+    if (!pf.pooled)   // (null also when the convolution was not split: its reduction could not do the pooling)
+      RC(tdx_maxpool2_ceil_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
+                               S.skip_ch[k], stream));
   }
-  RC(run_unit(6, ws + L.ep[2]));
+  const bool defer_ok = infer && !bf16 && (g_tdx_sample_fuse & 1);
+  TdxSplitDefer dfr{};   // the deferred result of the unit about to be resized (6, 8, 10, then 12)
+  RC(run_unit(6, ws + L.ep[2], defer_ok ? &dfr : nullptr));
   // decoder level k (0: dec3 .. 2: dec1): cat = [up(previous) | resize(e + t)], diffusion.py:135-154
   for (int k = 0; k < 3; ++k) {
     const int ua = 7 + 2 * k, ub = 8 + 2 * k;   // dec units of this level
@@ -682,20 +723,30 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const UnitDef& dp = S.units[prev];
     const int hw = da.hw, c_up = dp.cout, c_skip = S.skip_ch[skip_k];
     if (infer) {  // both halves in one launch (post-activation tensors: nothing to apply on load)
-      RC(tdx_bilinear_pair_fwd(ws + L.Y[prev], dp.hw, dp.hw, c_up, ws + L.Y[skip_u], ws + L.tp[skip_k],
-                               S.enc_hw[skip_k], S.enc_hw[skip_k], c_skip, ws + L.cat[k], B, hw, hw, st));
+      RC(tdx_bilinear_pair_fwd_ex(ws + L.Y[prev], &dfr, dp.hw, dp.hw, c_up, ws + L.Y[skip_u], ws + L.tp[skip_k],
+                                  S.enc_hw[skip_k], S.enc_hw[skip_k], c_skip, ws + L.cat[k], B, hw, hw, st));
+      dfr = TdxSplitDefer{};
     } else {
       RC(tdx_bilinear_ac_fwd(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
                              c_up, da.cin, 0, stream));
       TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[skip_k], 0));  // skip half: written during the encoder
     }
     RC(run_unit(ua, ws + L.cat[k]));
-    RC(run_unit(ub, ws + L.Y[ua]));
+    RC(run_unit(ub, ws + L.Y[ua], defer_ok ? &dfr : nullptr));
   }
   // resize to the output resolution (identity copy when equal) and the output convolution
-  RC(tdx_bilinear_ac_fwd(ws + L.Y[12], sc(12), sh(12), nullptr, ws + L.d1a, B, S.dec_hw[2], S.dec_hw[2],
-                         S.out_hw, S.out_hw, 64, 64, 0, stream));
-  RC(tdx_final_conv_fwd(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch, st));
+  if (dfr.splits > 0)   // sampling: the last unit's split-K partials are reduced by the resize itself
+    RC(tdx_bilinear_pair_fwd_ex(nullptr, &dfr, S.dec_hw[2], S.dec_hw[2], 64, nullptr, nullptr, 0, 0, 0, ws + L.d1a, B,
+                                S.out_hw, S.out_hw, st));
+  else
+    RC(tdx_bilinear_ac_fwd(ws + L.Y[12], sc(12), sh(12), nullptr, ws + L.d1a, B, S.dec_hw[2], S.dec_hw[2],
+                           S.out_hw, S.out_hw, 64, 64, 0, stream));
+  if (infer && u->ps.x)
+    RC(tdx_final_conv_fwd_psample(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch,
+                                  u->ps.x, u->ps.z, u->ps.coef, u->ps.t_idx, u->ps.seed, u->ps.philox, u->ps.counter_dec,
+                                  st));
+  else
+    RC(tdx_final_conv_fwd(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch, st));
 
   u->saved_batch = infer ? 0 : B;
   u->saved_mode = mode;
@@ -1039,12 +1090,86 @@ extern "C" int tdx_unet_eval_step(tdx_unet* u, const void* const* params, void* 
                                   tdx_stream_t stream) {
   if (!u || !x || !coef || !counter || !t_idx || !t_vec || !eps || batch <= 0 || n_elems <= 0)
     return TDX_E_BADARG;
-  RC(tdx_step_begin(counter, t_idx, t_vec, batch, stream));
-  RC(tdx_unet_forward(u, params, buffers, x, t_vec, cond, eps, workspace, workspace_bytes, batch,
-                      TDX_MODE_INFER, stream));
+  // Table mode (tdx_unet_prepare_sampling was called for this pack, batch and cond): ONE head kernel sets t and
+  // adds two table rows per sample into the workspace's projection slots - in place of step_begin, the time MLP and
+  // the three projections - and the update kernel advances the counter.
+  const bool tab = u->spec && u->tab && u->packed && u->tab_gen == u->pack_gen && u->tab_batch == batch &&
+                   u->tab_cond == cond && workspace &&
+                   workspace_bytes >= make_layout(*u->spec, batch).total * sizeof(float);
+  if (tab) {
+    const NetSpec& S = *u->spec;
+    const Layout L = make_layout(S, batch);
+    float* ws = reinterpret_cast<float*>(workspace);
+    const size_t T = (size_t)u->tab_T, w1 = S.skip_ch[0], w2 = S.skip_ch[1], w3 = S.skip_ch[2];
+    const float* t1 = u->tab;
+    const float* t2 = t1 + T * w1;
+    const float* t3 = t2 + T * w2;
+    const float* c1 = cond ? t3 + T * w3 : nullptr;
+    const float* c2 = cond ? c1 + (size_t)batch * w1 : nullptr;
+    const float* c3 = cond ? c2 + (size_t)batch * w2 : nullptr;
+    RC(tdx_sample_head(counter, t_idx, t_vec, batch, u->tab_T, u->kind, t1, t2, t3, c1, c2, c3, ws + L.tp[0],
+                       ws + L.tp[1], ws + L.tp[2], to_stream(stream)));
+  } else {
+    RC(tdx_step_begin(counter, t_idx, t_vec, batch, stream));
+  }
+  u->skip_time_path = tab;
+  // the UNets apply the update in final_conv's epilogue (one launch less); the latent MLP keeps the separate kernel
+  const bool fuse_ps = u->spec && (g_tdx_sample_fuse & 4) && n_elems == (int64_t)batch * u->spec->in_ch * u->spec->out_hw * u->spec->out_hw;
+  if (fuse_ps) u->ps = {x, z, coef, t_idx, philox_seed, z ? 0 : 1, tab ? counter : nullptr};
+  const int rc = tdx_unet_forward(u, params, buffers, x, t_vec, cond, eps, workspace, workspace_bytes, batch,
+                                  TDX_MODE_INFER, stream);
+  u->skip_time_path = false;
+  u->ps = {};
+  if (rc) return rc;
+  if (fuse_ps) return 0;
   // elementwise, so x is updated in place; both kernels skip the noise term at t == 0
+  if (tab) return tdx_p_sample_step_dec(x, x, eps, z, coef, t_idx, n_elems, philox_seed, counter, to_stream(stream));
   if (z) return tdx_p_sample_step(x, x, eps, z, coef, t_idx, n_elems, stream);
   return tdx_p_sample_step_philox(x, x, eps, coef, t_idx, n_elems, philox_seed, stream);
+}
+
+// Build the sampling tables for the CURRENT INFER pack (call after tdx_unet_pack / the first INFER forward, once
+// per sample() call, outside any stream capture: it may allocate).  T = number of diffusion steps (the counter
+// handed to tdx_unet_eval_step must stay below it); cond = the labels / text embeddings the eval steps will be
+// given (the same pointer: the cond part is computed from its contents NOW).
+extern "C" int tdx_unet_prepare_sampling(tdx_unet* u, const void* const* params, const void* cond, int batch, int T,
+                                         tdx_stream_t stream) {
+  if (!u || !params || batch <= 0 || batch > u->max_batch || T <= 0) return TDX_E_BADARG;
+  if (!u->spec) return TDX_E_SHAPE;   // the latent MLP runs its own fused time path
+  const bool needs_cond = u->kind == 1 || u->num_classes > 0;
+  if (needs_cond != (cond != nullptr)) return TDX_E_BADARG;
+  if (!u->packed) return TDX_E_STATE;
+  if (!g_tdx_sample_tables) { u->tab_gen = -1; return 0; }   // knob "sample_tables" = 0: A/B against the direct path
+  const NetSpec& S = *u->spec;
+  const size_t wsum = (size_t)S.skip_ch[0] + S.skip_ch[1] + S.skip_ch[2], td = S.time_dim;
+  const size_t scratch = std::max<size_t>(2 * (size_t)T + 3 * (size_t)T * td, (size_t)batch * td);
+  const size_t need = (size_t)T * wsum + (size_t)batch * wsum + scratch + 64;
+  if (need > u->tab_floats) {
+    if (u->tab) (void)hipFree(u->tab);
+    u->tab = nullptr;
+    u->tab_floats = 0;
+    hipError_t e = hipMalloc(&u->tab, need * sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    u->tab_floats = need;
+    u->tab_gen = -1;
+  }
+  const float* const* P = reinterpret_cast<const float* const*>(params);
+  hipStream_t st = to_stream(stream);
+  float* t1 = u->tab;
+  float* t2 = t1 + (size_t)T * S.skip_ch[0];
+  float* t3 = t2 + (size_t)T * S.skip_ch[1];
+  float* c1 = t3 + (size_t)T * S.skip_ch[2];
+  float* c2 = c1 + (size_t)batch * S.skip_ch[0];
+  float* c3 = c2 + (size_t)batch * S.skip_ch[1];
+  float* scr = c3 + (size_t)batch * S.skip_ch[2];
+  if (u->tab_gen != u->pack_gen || u->tab_T != T || u->tab_batch != batch)   // (the cond block moves with T and batch)
+    RC(tdx_time_tables_build(u->kind, P, T, S.time_dim, t1, t2, t3, scr, st));
+  if (cond) RC(tdx_time_tables_cond(u->kind, P, cond, batch, S.time_dim, c1, c2, c3, scr, st));
+  u->tab_T = T;
+  u->tab_batch = batch;
+  u->tab_cond = cond;
+  u->tab_gen = u->pack_gen;
+  return 0;
 }
 
 extern "C" int tdx_unet_request_input_grad(tdx_unet* u, float* g_x) {

@@ -178,6 +178,10 @@ def sample_loop(noise_model, diffusion: ForwardProcess, device, n_samples: int, 
                     step_kernels(False)
             return run
 
+        if one_call and hasattr(noise_model, "_prepare_sampling"):
+            # per-t / per-sample tables of the (linear) time projections: one look-up kernel per reverse step in
+            # place of the step counter, the time MLP and the projections (tdx_unet_prepare_sampling)
+            noise_model._prepare_sampling(x, y_dev, T)
         unroll = min(GRAPH_STEPS, T)
         counter.fill_(T - 1)
         graph = capture(steps(unroll))

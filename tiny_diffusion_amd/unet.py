@@ -505,6 +505,24 @@ class NoiseModelBase(nn.Module):
                                      plan.workspace.data_ptr(), plan.ws_bytes, B, philox_seed, st),
               "tdx_unet_eval_step")
 
+    def _prepare_sampling(self, x, y, T: int):
+        """Once per sample() call, before the reverse loop (and before any graph capture): the per-t table of
+        ``time_proj_k(time MLP(t))`` and the per-sample table of ``W_k c`` (c = class / text embedding), so that
+        every reverse step replaces the time path's launches by one look-up (tdx_unet_prepare_sampling; SURVEY.md 7:
+        the projections are linear in the embedding).  ``y`` must be the very tensor later handed to
+        ``_run_eval_step`` (the tables are tied to its pointer).  No-op for the latent MLP."""
+        if self._arch.kind == KIND_LATENT:
+            return
+        B = x.shape[0]
+        plan = self._plan(B, x.device, self._input_hw(x))
+        self._apply_precision(plan)
+        pptr, ptens = self._param_ptrs()
+        bptr, btens = self._buffer_ptrs()
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        self._refresh_infer_pack(plan, pptr, ptens, bptr, btens, st)
+        check(lib.tdx_unet_prepare_sampling(plan.handle, pptr, None if y is None else y.data_ptr(), B, int(T), st),
+              "tdx_unet_prepare_sampling")
+
     def _run_backward(self, plan: _Plan, d_out, grad_views, stage_lo: int = 0, stage_hi: Optional[int] = None):
         pptr, _ = self._param_ptrs()
         gt = [None if n is None else grad_views[n] for n in self._slot_names]
