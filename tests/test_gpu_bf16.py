@@ -173,7 +173,10 @@ def _check_against_fp32(m, args_gpu, noise, eps_ref, loss_ref, grads_ref, tag):
     cos.sort()
     med = cos[len(cos) // 2][0]
     print(f"{tag}: gradient cosine vs the fp32 oracle: worst {cos[:3]}, median {med:.5f}")
-    assert cos[0][0] >= 0.95 and med >= 0.99, (cos[:3], med)
+    # bf16 STORAGE of activations and activation gradients (round 3) roughly doubles the distance to the fp32
+    # oracle that bf16 MFMA operands alone had: measured worst / median cosine 0.940 / 0.9906 (LAION 64x64 at B = 2,
+    # the most sensitive case), 0.962-0.997 / >= 0.9987 everywhere else; eps_hat MSE 5e-5 .. 3.8e-4 against the 5e-4 gate
+    assert cos[0][0] >= 0.93 and med >= 0.99, (cos[:3], med)
 
 
 def test_bf16_mnist_unet_against_fp32_golden(golden_dir):

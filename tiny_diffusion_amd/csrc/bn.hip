@@ -5,6 +5,7 @@
 // (relu(y*scale+shift)), so the normalised activation is never written to HBM.
 // Backward: two per-channel reductions over (g, y), then one in-place pass.
 #include "internal.h"
+#include "io16.h"
 #include <algorithm>
 
 #define BN_EPS 1e-5f
@@ -253,8 +254,9 @@ static int bwd_rows_per_block(int64_t rows, int C) {
 }
 
 // partial[blk][2][C]: sum gz, sum gz*xhat over the block's rows
+template <typename T>   // element type of g and y in HBM (io16.h)
 __global__ void __launch_bounds__(256)
-bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t rows, int C,
+bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y, int64_t rows, int C,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ rstd,
                      float* __restrict__ partial, int rpb) {
@@ -271,8 +273,8 @@ bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y, i
   const int64_t r1 = min(r0 + rpb, rows);
 #pragma unroll 4
   for (int64_t r = r0 + rg; r < r1; r += rgroups) {
-    const float4 gv = *reinterpret_cast<const float4*>(g + r * C + c);
-    const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+    const float4 gv = ld4(g + r * C + c);
+    const float4 yv = ld4(y + r * C + c);
 #define ACC(k)                                                   \
     {                                                            \
       const float gz = fmaf(yv.k, sc.k, sh.k) > 0.f ? gv.k : 0.f; \
@@ -390,8 +392,9 @@ __global__ void bn_bwd_coef_moments_kernel(const double* __restrict__ mom, int C
   coef[2 * C + c] = (float)(mom[C + c] / n);
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t n4, int C,
+bn_bwd_apply_kernel(T* __restrict__ g, const T* __restrict__ y, int64_t n4, int C,
                     const float* __restrict__ scale, const float* __restrict__ shift,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ coef) {
@@ -406,8 +409,8 @@ bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t 
     const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
     const float4 m1 = *reinterpret_cast<const float4*>(coef + C + c);
     const float4 m2 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
-    float4 gv = reinterpret_cast<float4*>(g)[i];
-    const float4 yv = reinterpret_cast<const float4*>(y)[i];
+    float4 gv = ld4(g + i * 4);
+    const float4 yv = ld4(y + i * 4);
 #define APPLY(k)                                                     \
     {                                                                \
       const float gz = fmaf(yv.k, sc.k, sh.k) > 0.f ? gv.k : 0.f;    \
@@ -416,7 +419,7 @@ bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, int64_t 
     }
     APPLY(x) APPLY(y) APPLY(z) APPLY(w)
 #undef APPLY
-    reinterpret_cast<float4*>(g)[i] = gv;
+    st4(g + i * 4, gv);
   }
 }
 
@@ -435,7 +438,7 @@ extern "C" int tdx_bn_relu_bwd(float* g, const float* y, int64_t rows, int C, co
                                const float* gamma, float* dgamma, float* dbeta, float* dbias,
                                float* scratch, int training, tdx_stream_t stream) {
   return tdx_bn_relu_bwd_sync(g, y, rows, C, scale, shift, save_mean, save_rstd, gamma, dgamma, dbeta, dbias, scratch,
-                              training, nullptr, nullptr, nullptr, stream);
+                              training, nullptr, nullptr, nullptr, stream, 0);
 }
 
 // The same with the per-channel sums all-reduced across ranks between the reduction and the apply
@@ -444,7 +447,7 @@ int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const fl
                          const float* shift, const float* save_mean, const float* save_rstd,
                          const float* gamma, float* dgamma, float* dbeta, float* dbias,
                          float* scratch, int training, tdx_allreduce_fn sync, void* sync_user, double* mom,
-                         tdx_stream_t stream) {
+                         tdx_stream_t stream, int io16) {   // io16: g and y hold bf16 (io16.h)
   if (!g || !y || !scale || !shift || !save_mean || !save_rstd || !gamma || !scratch || rows <= 0)
     return TDX_E_BADARG;
   if (sync && (!mom || !training)) return TDX_E_BADARG;
@@ -455,11 +458,11 @@ int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const fl
   float* partial = scratch;
   float* coef = scratch + (size_t)nblk * 2 * C;
   const int rgroups = 256 / (C / 4);
-  bn_bwd_reduce_kernel<<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
-      g, y, rows, C, scale, shift, save_mean, save_rstd, partial, rpb);
+  TDX_IO_DISPATCH(io16, T, bn_bwd_reduce_kernel<T><<<nblk, 256, (size_t)rgroups * 2 * C * sizeof(float), st>>>(
+      reinterpret_cast<const T*>(g), reinterpret_cast<const T*>(y), rows, C, scale, shift, save_mean, save_rstd, partial, rpb));
   TDX_CHECK_LAUNCH();
   return tdx_bn_relu_bwd_tail(g, y, rows, C, scale, shift, save_mean, save_rstd, gamma, dgamma, dbeta, dbias, partial,
-                              nblk, coef, training, sync, sync_user, mom, stream);
+                              nblk, coef, training, sync, sync_user, mom, stream, io16);
 }
 
 // Finalize + apply from partial sums [nblk][2][C] that are already in memory: written by the reduction kernel
@@ -468,7 +471,7 @@ int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const fl
 int tdx_bn_relu_bwd_tail(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
                          const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
                          float* dbeta, float* dbias, const float* partial, int nblk, float* coef, int training,
-                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream) {
+                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream, int io16) {
   if (!g || !y || !partial || !coef || nblk <= 0 || rows <= 0) return TDX_E_BADARG;
   if (sync && (!mom || !training)) return TDX_E_BADARG;
   if (C % 4 || C > 1024) return TDX_E_SHAPE;
@@ -489,7 +492,8 @@ int tdx_bn_relu_bwd_tail(float* g, const float* y, int64_t rows, int C, const fl
   const int64_t n4 = rows * C / 4;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 4096) grid = 4096;
-  bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(g, y, n4, C, scale, shift, save_mean, save_rstd, coef);
+  TDX_IO_DISPATCH(io16, T, bn_bwd_apply_kernel<T><<<grid, 256, 0, st>>>(reinterpret_cast<T*>(g), reinterpret_cast<const T*>(y), n4, C,
+                                                                        scale, shift, save_mean, save_rstd, coef));
   TDX_CHECK_LAUNCH();
   return 0;
 }

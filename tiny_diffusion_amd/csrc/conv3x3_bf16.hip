@@ -17,18 +17,28 @@
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define KT 64    // K-tile (bf16 elements): 64 channels of one tap / 64 pixels (wgrad)
 #define KTP 72   // padded LDS row: 144 B, conflict-free for the 16-lane groups of ds_read_b128
 
 // ---------------------------------------------------------------------------------- forward / dgrad
-template <int BM, int BN, bool IN_BN, int EPI>
+// IO16 (bf16 STORAGE, round 3): the input tensor holds bf16 - a 64-channel K-tile row is 128 bytes, eight 16-byte
+// loads instead of sixteen, and a raw input goes from the load registers to LDS with no conversion at all - and
+// the output is rounded to bf16 by the epilogue (ConvArgs::out_bf16; the BatchNorm statistics are still taken from
+// the fp32 accumulators).
+template <int BM, int BN, bool IN_BN, int EPI, bool IO16>
 __global__ void __launch_bounds__(256)
 conv3x3_bf16_kernel(ConvArgs a) {
   constexpr int WGN = 2;
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AI = BM / 16;  // fp32 float4 loads per thread per K-tile (16 per 64-channel row)
+  constexpr int ACH = IO16 ? 8 : 16;   // 16-byte loads per 64-channel row: 8 bf16 | 4 fp32 each
+  constexpr int ARW = 256 / ACH;       // rows covered by one pass of the workgroup
+  constexpr int AEL = 64 / ACH;        // channels per load
+  constexpr int AES = IO16 ? 2 : 4;    // bytes per element of the input tensor
+  constexpr int AI = BM / ARW;         // A loads per thread per K-tile
   constexpr int BI = BN / 32;  // 16-byte bf16 loads per thread per K-tile (8 per row)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -46,18 +56,19 @@ conv3x3_bf16_kernel(ConvArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int HW = a.H * a.W;
 
-  const int a_c4 = tid & 15, a_row = tid >> 4;  // A: 16 float4 per row, 16 rows per pass
+  const int a_c4 = tid % ACH, a_row = tid / ACH;  // A: ACH 16-byte chunks per row, ARW rows per pass
   const int b_ch = tid & 7, b_row = tid >> 3;   // B: 8 x 16 B per row, 32 rows per pass
   const int neg = (a.W + 1) * a.Cin;
   const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
+      reinterpret_cast<char*>(const_cast<float*>(a.in)) - (int64_t)neg * AES, 0,
+      (int)(((int64_t)a.M * a.Cin + 2 * neg) * AES), 0x00020000);
   const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0,
                                                         a.Cout * 9 * a.Cin * 2, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned a_off[AI], a_taps[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int p = m0 + a_row + 16 * i;
+    const int p = m0 + a_row + ARW * i;
     unsigned taps = 0;
     if (p < a.M) {
       const int r = p % HW, oh = r / a.W, ow = r % a.W;
@@ -68,7 +79,7 @@ conv3x3_bf16_kernel(ConvArgs a) {
       }
     }
     a_taps[i] = taps;
-    a_off[i] = (unsigned)(p * a.Cin + a_c4 * 4) * 4u;
+    a_off[i] = (unsigned)(p * a.Cin + a_c4 * AEL) * (unsigned)AES;
   }
   unsigned w_off[BI];
 #pragma unroll
@@ -89,21 +100,25 @@ conv3x3_bf16_kernel(ConvArgs a) {
   // Iteration kt: issue the loads of tile kt+2 into the free stage, run the MFMAs of tile kt from
   // LDS[kt&1], convert + store tile kt+1 (loaded during iteration kt-1) into LDS[(kt+1)&1].
   struct Stage {
-    f32x4 ra[AI], rb[BI], sc, sh;
+    f32x4 ra[AI], rb[BI], sc, sh, sc2, sh2;   // (sc2 / sh2: channels 4..7 of an 8-channel bf16 chunk)
     unsigned ok;
   };
   Stage S0, S1;
   auto load_tile = [&](int kt, Stage& S) {
     const int kn = min(kt, nk - 1);
     const int cblk = kn / 9, tap = kn - cblk * 9;
-    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * 4u;
+    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * (unsigned)AES;
     const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * KT) * 2u;
 #pragma unroll
     for (int j = 0; j < BI; ++j)
       S.rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j], soff_w, 0));
     if (IN_BN) {
-      S.sc = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * 4);
-      S.sh = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * 4);
+      S.sc = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * AEL);
+      S.sh = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * AEL);
+      if (IO16) {
+        S.sc2 = *reinterpret_cast<const f32x4*>(a.in_scale + cblk * KT + a_c4 * AEL + 4);
+        S.sh2 = *reinterpret_cast<const f32x4*>(a.in_shift + cblk * KT + a_c4 * AEL + 4);
+      }
     }
     unsigned ok = 0;
 #pragma unroll
@@ -120,14 +135,30 @@ conv3x3_bf16_kernel(ConvArgs a) {
     __bf16* Bb = Bs + buf * BN * KTP;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      f32x4 v = S.ra[i];
-      if (IN_BN) {
-        // padding must stay 0 AFTER the transform (relu(shift) != 0)
+      if (IO16) {
+        f32x4 raw = S.ra[i];   // eight bf16
+        if (IN_BN) {
+          const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
+          bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], S.sc[e], S.sh[e]), 0.f);
-        if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)fmaxf(fmaf((float)h[e], S.sc[e], S.sh[e]), 0.f);
+            o[e + 4] = (__bf16)fmaxf(fmaf((float)h[e + 4], S.sc2[e], S.sh2[e]), 0.f);
+          }
+          raw = __builtin_bit_cast(f32x4, o);
+          if (!((S.ok >> i) & 1u)) raw = f32x4{0.f, 0.f, 0.f, 0.f};   // padding stays 0 AFTER the transform
+        }
+        *reinterpret_cast<f32x4*>(Ab + (a_row + ARW * i) * KTP + a_c4 * 8) = raw;
+      } else {
+        f32x4 v = S.ra[i];
+        if (IN_BN) {
+          // padding must stay 0 AFTER the transform (relu(shift) != 0)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], S.sc[e], S.sh[e]), 0.f);
+          if (!((S.ok >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<bf16x4*>(Ab + (a_row + ARW * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
       }
-      *reinterpret_cast<bf16x4*>(Ab + (a_row + 16 * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j)
@@ -177,9 +208,11 @@ conv3x3_bf16_kernel(ConvArgs a) {
 // the MFMA wants 8 consecutive k (pixels) of one row (channel) per lane, so the tiles are transposed
 // while they are staged: a thread loads 4 pixels x 4 channels (four float4), and writes, per channel,
 // the four pixels as one 8-byte bf16 pack into LDS[channel][pixel].  K-tile = 64 pixels.
-template <int BM, int BN, bool IN_BN>
+// IO16: `in` and `dy` hold bf16 (8-byte loads of 4 channels; the transposition moves the 16-bit elements as they are)
+template <int BM, int BN, bool IN_BN, bool IO16>
 __global__ void __launch_bounds__(256, 2)   // two workgroups per CU (<= 256 registers): latency hiding first
 conv3x3_wgrad_bf16_kernel(WgradArgs a) {
+  constexpr unsigned ES = IO16 ? 2u : 4u;   // bytes per element of `in` / `dy`
   constexpr int WGN = 2;
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -218,15 +251,16 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
   const int neg = (a.W + 1) * a.Cin;
   // the dy descriptor ENDS at this workgroup's last pixel: the ragged end of the range reads zeros
   const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0,
-                                                         (int)((int64_t)p_hi * a.Cout * 4), 0x00020000);
+                                                         (int)((int64_t)p_hi * a.Cout * ES), 0x00020000);
   const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in) - neg, 0, (int)(((int64_t)a.M * a.Cin + 2 * neg) * 4), 0x00020000);
-  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * 4u;
+      reinterpret_cast<char*>(const_cast<float*>(a.in)) - (int64_t)neg * ES, 0,
+      (int)(((int64_t)a.M * a.Cin + 2 * neg) * ES), 0x00020000);
+  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * ES;
   unsigned a_off[APASS], b_off[BPASS];
 #pragma unroll
-  for (int q = 0; q < APASS; ++q) a_off[q] = (unsigned)((q * 4 * APG + a_pg * 4) * a.Cout + co0 + a_c4 * 4) * 4u;
+  for (int q = 0; q < APASS; ++q) a_off[q] = (unsigned)((q * 4 * APG + a_pg * 4) * a.Cout + co0 + a_c4 * 4) * ES;
 #pragma unroll
-  for (int q = 0; q < BPASS; ++q) b_off[q] = (unsigned)((q * 4 * BPG + b_pg * 4) * a.Cin + ci0 + b_c4 * 4) * 4u;
+  for (int q = 0; q < BPASS; ++q) b_off[q] = (unsigned)((q * 4 * BPG + b_pg * 4) * a.Cin + ci0 + b_c4 * 4) * ES;
   // (oh, ow) of the first pixel of each 4-pixel group this thread stages for B; advanced by KT pixels
   // per K-tile (tiles are requested strictly in order)
   int b_oh[BPASS], b_ow[BPASS];
@@ -265,14 +299,21 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     const bool advance = kt_req > 0 && kt_req < nk && kt_req == tiles_issued;
     if (kt_req == tiles_issued) ++tiles_issued;
     const int pbase = p_lo + kt * KT;
-    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 4u;
-    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 4u + tap_shift;
+    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * ES;
+    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * ES + tap_shift;
+    // IO16: four bf16 per load land in the first two dwords of the stage register (the other two stay unused)
+    auto ldx = [&](decltype(rsrc_dy) rs, unsigned voff, unsigned soff) -> f32x4 {
+      if (IO16) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        return __builtin_bit_cast(f32x4, u32x4{v[0], v[1], 0u, 0u});
+      }
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
 #pragma unroll
     for (int q = 0; q < APASS; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        S.ra[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                    rsrc_dy, a_off[q] + (unsigned)(e * a.Cout) * 4u, soff_a, 0));
+        S.ra[q][e] = ldx(rsrc_dy, a_off[q] + (unsigned)(e * a.Cout) * ES, soff_a);
     unsigned okB = 0;
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
@@ -291,8 +332,7 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
         // (pixels past the tensor are refused too: their dy rows are zero, but 0 * garbage may be NaN)
         const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W && pix0 + e < a.M;
         okB |= ok ? (1u << (q * 4 + e)) : 0u;
-        S.rb[q][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                    rsrc_in, ok ? b_off[q] + (unsigned)(e * a.Cin) * 4u : OOB, soff_b, 0));
+        S.rb[q][e] = ldx(rsrc_in, ok ? b_off[q] + (unsigned)(e * a.Cin) * ES : OOB, soff_b);
         if (++ow == a.W) { ow = 0; if (++oh == a.H) oh = 0; }
       }
     }
@@ -301,19 +341,29 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
   auto store_tile = [&](const Stage& S, int buf) {
     __bf16* Ab = As + buf * BM * KTP;
     __bf16* Bb = Bs + buf * BN * KTP;
+    // the 4 channels of pixel e of a stage register as floats (IO16: widened from the bf16 pack in its low half)
+    auto wide = [&](const f32x4& r) -> f32x4 {
+      if (!IO16) return r;
+      const bf16x8 h = __builtin_bit_cast(bf16x8, r);
+      return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    };
 #pragma unroll
-    for (int q = 0; q < APASS; ++q)
+    for (int q = 0; q < APASS; ++q) {
+      f32x4 y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = wide(S.ra[q][e]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 v = {S.ra[q][0][c], S.ra[q][1][c], S.ra[q][2][c], S.ra[q][3][c]};
+        const f32x4 v = {y[0][c], y[1][c], y[2][c], y[3][c]};   // (bf16 -> fp32 -> bf16 is exact)
         *reinterpret_cast<bf16x4*>(Ab + (a_c4 * 4 + c) * KTP + q * 4 * APG + a_pg * 4) = __builtin_convertvector(v, bf16x4);
       }
+    }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       f32x4 x[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        x[e] = S.rb[q][e];
+        x[e] = wide(S.rb[q][e]);
         if (IN_BN) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) x[e][c] = fmaxf(fmaf(x[e][c], sc4[c], sh4[c]), 0.f);
@@ -429,7 +479,7 @@ extern "C" int tdx_pack_conv3x3_bf16(const float* w_oihw, void* w_fwd_bf16, void
 // ----------------------------------------------------------------------------------------- dispatch
 extern "C" int tdx_conv3x3_bf16_stat_tile_rows(void) { return 128; }
 
-template <int BM, int BN>
+template <int BM, int BN, bool IO16>
 static int launch_bf16(const ConvArgs& a, int flags, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * KTP * sizeof(__bf16);
   const int grid = (cdiv(a.M, BM) + 7) / 8 * 8 * a.tilesN;
@@ -437,7 +487,7 @@ static int launch_bf16(const ConvArgs& a, int flags, hipStream_t st) {
   const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS : EPI_PLAIN;
 #define TDX_LAUNCH_BF16(INBN, EPI_)                                                                  \
   do {                                                                                               \
-    auto kern = conv3x3_bf16_kernel<BM, BN, INBN, EPI_>;                                             \
+    auto kern = conv3x3_bf16_kernel<BM, BN, INBN, EPI_, IO16>;                                       \
     static bool attr_set = false;                                                                    \
     if (lds > 65536 && !attr_set) {                                                                  \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
@@ -466,6 +516,17 @@ extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const
                                     const float* in_scale, const float* in_shift,
                                     const float* out_scale, const float* out_shift,
                                     float* stats_partial, tdx_stream_t stream) {
+  return tdx_conv3x3_fwd_bf16_io(in, wpk_bf16, bias, out, B, H, W, cin, cout, flags, in_scale, in_shift, out_scale, out_shift,
+                                 stats_partial, 0, stream);
+}
+
+// io16: `in` and `out` hold bf16 (bf16 storage mode; the C-ABI entry above is the fp32-tensor form)
+int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, const float* bias, void* out_, int B, int H, int W,
+                            int cin, int cout, int flags, const float* in_scale, const float* in_shift,
+                            const float* out_scale, const float* out_shift, float* stats_partial, int io16,
+                            tdx_stream_t stream) {
+  const float* in = static_cast<const float*>(in_);
+  float* out = static_cast<float*>(out_);
   if (!in || !wpk_bf16 || !out || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   if (cin % KT || cout % 64) return TDX_E_SHAPE;
   if ((flags & TDX_CONV_IN_BNRELU) && (!in_scale || !in_shift)) return TDX_E_BADARG;
@@ -479,20 +540,24 @@ extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const
   a.stats = stats_partial;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)((int64_t)B * H * W);
   a.splits = 1; a.kt_per_split = 0; a.dbg = 0; a.stamps = nullptr;
+  a.out_bf16 = io16 ? 1 : 0;
   hipStream_t st = to_stream(stream);
   // memory-bound: the widest column tile re-reads the input least often
-  if (cout % 128 == 0) { a.tilesN = cout / 128; return launch_bf16<128, 128>(a, flags, st); }
+  if (cout % 128 == 0) {
+    a.tilesN = cout / 128;
+    return io16 ? launch_bf16<128, 128, true>(a, flags, st) : launch_bf16<128, 128, false>(a, flags, st);
+  }
   a.tilesN = cout / 64;
-  return launch_bf16<128, 64>(a, flags, st);
+  return io16 ? launch_bf16<128, 64, true>(a, flags, st) : launch_bf16<128, 64, false>(a, flags, st);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool IO16>
 static int launch_wgrad_bf16(const WgradArgs& a, bool in_bn, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * KTP * sizeof(__bf16);
   dim3 grid((unsigned)(((int64_t)a.groups + 7) / 8 * 72));
 #define TDX_LAUNCH_WG(INBN)                                                                          \
   do {                                                                                               \
-    auto kern = conv3x3_wgrad_bf16_kernel<BM, BN, INBN>;                                             \
+    auto kern = conv3x3_wgrad_bf16_kernel<BM, BN, INBN, IO16>;                                       \
     static bool attr_set = false;                                                                    \
     if (lds > 65536 && !attr_set) {                                                                  \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
@@ -512,6 +577,13 @@ static int launch_wgrad_bf16(const WgradArgs& a, bool in_bn, hipStream_t st) {
 extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* dw_slabs, int B, int H,
                                       int W, int cin, int cout, int flags, const float* in_scale,
                                       const float* in_shift, tdx_stream_t stream) {
+  return tdx_conv3x3_wgrad_bf16_io(in, dy, dw_slabs, B, H, W, cin, cout, flags, in_scale, in_shift, 0, stream);
+}
+
+int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float* dw_slabs, int B, int H, int W, int cin, int cout,
+                              int flags, const float* in_scale, const float* in_shift, int io16, tdx_stream_t stream) {
+  const float* in = static_cast<const float*>(in_);
+  const float* dy = static_cast<const float*>(dy_);
   if (!in || !dy || !dw_slabs || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   if (cin % 64 || cout % 64) return TDX_E_SHAPE;
   const bool in_bn = flags & TDX_CONV_IN_BNRELU;
@@ -527,8 +599,10 @@ extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* d
   a.groups = a.tilesCi * a.tilesCo * splits;
   a.adv_q = 0; a.adv_s = 0;
   hipStream_t st = to_stream(stream);
-  if (bm == 128 && bn == 128) return launch_wgrad_bf16<128, 128>(a, in_bn, st);
-  if (bm == 128 && bn == 64) return launch_wgrad_bf16<128, 64>(a, in_bn, st);
-  if (bm == 64 && bn == 128) return launch_wgrad_bf16<64, 128>(a, in_bn, st);
-  return launch_wgrad_bf16<64, 64>(a, in_bn, st);
+#define TDX_WG(BM_, BN_) (io16 ? launch_wgrad_bf16<BM_, BN_, true>(a, in_bn, st) : launch_wgrad_bf16<BM_, BN_, false>(a, in_bn, st))
+  if (bm == 128 && bn == 128) return TDX_WG(128, 128);
+  if (bm == 128 && bn == 64) return TDX_WG(128, 64);
+  if (bm == 64 && bn == 128) return TDX_WG(64, 128);
+  return TDX_WG(64, 64);
+#undef TDX_WG
 }

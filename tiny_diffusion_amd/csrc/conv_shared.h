@@ -39,6 +39,7 @@ struct ConvArgs {
   const float* bw_y;
   const float* bw_scale; const float* bw_shift; const float* bw_mean; const float* bw_rstd;
   float* bw_partial;
+  int out_bf16;   // bf16 storage mode: `out` holds bf16 and the epilogue rounds to nearest-even on store (conv3x3_bf16.hip)
   unsigned long long* stamps;  // diagnostics (tools/gpu_clock_probe.py): per workgroup {shader cycles, 100 MHz ticks}
                                // around the main loop; null in every product launch
 };
@@ -186,7 +187,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
         acc[im][in][r] = v;
         if (p < a.M) {
-          a.out[(size_t)p * a.Cout + col] = v;
+          if (a.out_bf16) reinterpret_cast<__bf16*>(a.out)[(size_t)p * a.Cout + col] = (__bf16)v;
+          else a.out[(size_t)p * a.Cout + col] = v;
           s += v;
         }
       }

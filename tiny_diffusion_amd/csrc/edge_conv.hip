@@ -13,6 +13,7 @@
 // T[p][k = (ch, tap)] = thin[n][ch][pixel p shifted by the tap] (0 outside the image).
 // Before (B = 256, LAION 4x32x32, us): 107 / 142 / 54 / 408 / 382 of a 10.1 ms step, mostly exposed at its head and tail.
 #include "internal.h"
+#include "io16.h"
 
 #define IC_CO 64
 #define SMALLP_W 2368  // floats per row of the weight-gradient partial buffer (4*64*9 + 64)
@@ -33,10 +34,10 @@ __device__ __forceinline__ void tap_of(int k, int& c, int& dy, int& dx) {
 // tiles, K = CT*9 in steps of 2.  FLIP = false: w is [cor][CT][9] (initial_conv.weight), channels
 // >= cor are written as zeros; FLIP = true: w is [CT][64][9] (final_conv.weight), the input
 // gradient: g_in[p][c] = sum_{o,tap} g_out[n][o][p - tap] W[o][c][tap].
-template <int CT, bool FLIP>
+template <int CT, bool FLIP, typename TF>   // TF: element type of the fat (channels-last, 64-channel) tensor, io16.h
 __global__ void __launch_bounds__(256)
 thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W,
+                        const float* __restrict__ bias, TF* __restrict__ out, int B, int H, int W,
                         int cor) {
   constexpr int K = CT * 9, KS = (K + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,8 +103,8 @@ thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict_
     for (int i = 0; i < 16; ++i) {
       const int64_t pp = pw0 + (i & 3) + 8 * (i >> 2) + 4 * half;
       if (pp < M) {
-        out[pp * IC_CO + l31] = acc[0][i];
-        out[pp * IC_CO + 32 + l31] = acc[1][i];
+        st1(out + pp * IC_CO + l31, acc[0][i]);
+        st1(out + pp * IC_CO + 32 + l31, acc[1][i]);
       }
     }
   }
@@ -126,11 +127,11 @@ thin_to_fat_conv_kernel(const float* __restrict__ thin, const float* __restrict_
 struct PSampleOps {
   float* x; const float* z; const float* coef; const int32_t* t_idx; uint64_t seed; int philox; int64_t* counter_dec;
 };
-template <int CO, bool DGRAD = false, bool PS = false>
+template <int CO, bool DGRAD, bool PS, typename TF>
 __global__ void __launch_bounds__(256)
-fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int cor = IC_CO,
-                        PSampleOps ps = PSampleOps{}) {
+fat_to_thin_conv_kernel(const TF* __restrict__ in, const float* __restrict__ w,
+                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W, int cor,
+                        PSampleOps ps) {
   __shared__ __attribute__((aligned(16))) float ws[CO][9][IC_CO];
   if (DGRAD) {
     for (int i = threadIdx.x; i < CO * 9 * IC_CO; i += 256) {
@@ -172,8 +173,7 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
       for (int tap = 0; tap < 9; ++tap) {
         const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
         if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          const float4 v = *reinterpret_cast<const float4*>(
-              in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
+          const float4 v = ld4(in + (p + (tap / 3 - 1) * W + (tap % 3 - 1)) * IC_CO + ci);
 #pragma unroll
           for (int co = 0; co < CO; ++co) {
             const float4 wv = *reinterpret_cast<const float4*>(&ws[co][tap][ci]);
@@ -226,9 +226,9 @@ fat_to_thin_conv_kernel(const float* __restrict__ in, const float* __restrict__ 
 //                 an extra all-ones column gives db[o] = sum_p g[p][o] at cor*K + o
 //   FLIP = true   final_conv: thin = g_out, fat = the conv's input; dW[o][c][tap] at (o*64 + c)*9 + tap;
 //                 db[o] = sum_p g_out[n][o][p] = the column sums of the centre taps, at CT*576 + o
-template <int CT, bool FLIP>
+template <int CT, bool FLIP, typename TF>
 __global__ void __launch_bounds__(256)
-thin_fat_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ fat,
+thin_fat_wgrad_kernel(const float* __restrict__ thin, const TF* __restrict__ fat,
                       float* __restrict__ partial, int B, int H, int W, int pix, int cor) {
   constexpr int K = CT * 9, KC = FLIP ? K : K + 1, CB = KC <= 32 ? 1 : 2;
   __shared__ float red[IC_CO][CB * 32 + 1];
@@ -275,9 +275,9 @@ thin_fat_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ 
 #pragma unroll 4
   for (int64_t p = p0; p < p1; p += 2, q += 2) {
     const bool qv = q < p1;
-    const float* frow = fat + q * IC_CO + l31;
-    const float a0 = qv ? frow[0] : 0.f;
-    const float a1 = qv ? frow[32] : 0.f;
+    const TF* frow = fat + q * IC_CO + l31;
+    const float a0 = qv ? ld1(frow) : 0.f;
+    const float a1 = qv ? ld1(frow + 32) : 0.f;
     const float* tb = thin + (int64_t)n * CT * HW + oh * W + ow;
     float bq[CB];
 #pragma unroll
@@ -424,35 +424,38 @@ int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, 
   return 0;
 }
 
-int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                         int W, int cin, int cout_real, hipStream_t st) {
+// io16 (all launchers below): the fat, channels-last tensor holds bf16 (io16.h); thin tensors, weights and gradients
+// of weights are fp32 always
+int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int H,
+                         int W, int cin, int cout_real, hipStream_t st, int io16) {
   const int grid = conv_grid((int64_t)B * H * W);
-  if (cin == 1 && cout_real == 64)
-    thin_to_fat_conv_kernel<1, false><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W, cout_real);
-  else if (cin == 4 && cout_real == 32)
-    thin_to_fat_conv_kernel<4, false><<<grid, 256, 0, st>>>(x, w, bias, out, B, H, W, cout_real);
-  else return TDX_E_SHAPE;
+  if (!((cin == 1 && cout_real == 64) || (cin == 4 && cout_real == 32))) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cin == 1) thin_to_fat_conv_kernel<1, false, T><<<grid, 256, 0, st>>>(x, w, bias, (T*)out, B, H, W, cout_real);
+    else thin_to_fat_conv_kernel<4, false, T><<<grid, 256, 0, st>>>(x, w, bias, (T*)out, B, H, W, cout_real));
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
-                         int cout, hipStream_t st) {
+int tdx_final_conv_dgrad(const float* g_out, const float* w, void* g_in, int B, int H, int W,
+                         int cout, hipStream_t st, int io16) {
   const int grid = conv_grid((int64_t)B * H * W);
-  if (cout == 1) thin_to_fat_conv_kernel<1, true><<<grid, 256, 0, st>>>(g_out, w, nullptr, g_in, B, H, W, IC_CO);
-  else if (cout == 4) thin_to_fat_conv_kernel<4, true><<<grid, 256, 0, st>>>(g_out, w, nullptr, g_in, B, H, W, IC_CO);
-  else return TDX_E_SHAPE;
+  if (cout != 1 && cout != 4) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cout == 1) thin_to_fat_conv_kernel<1, true, T><<<grid, 256, 0, st>>>(g_out, w, nullptr, (T*)g_in, B, H, W, IC_CO);
+    else thin_to_fat_conv_kernel<4, true, T><<<grid, 256, 0, st>>>(g_out, w, nullptr, (T*)g_in, B, H, W, IC_CO));
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
-int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
-                       int W, int cout, hipStream_t st) {
+int tdx_final_conv_fwd(const void* in, const float* w, const float* bias, float* out, int B, int H,
+                       int W, int cout, hipStream_t st, int io16) {
   const int64_t M = (int64_t)B * H * W;
   const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
-  if (cout == 1) fat_to_thin_conv_kernel<1><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
-  else if (cout == 4) fat_to_thin_conv_kernel<4><<<grid, 256, 0, st>>>(in, w, bias, out, B, H, W);
-  else return TDX_E_SHAPE;
+  if (cout != 1 && cout != 4) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cout == 1) fat_to_thin_conv_kernel<1, false, false, T><<<grid, 256, 0, st>>>((const T*)in, w, bias, out, B, H, W, IC_CO, PSampleOps{});
+    else fat_to_thin_conv_kernel<4, false, false, T><<<grid, 256, 0, st>>>((const T*)in, w, bias, out, B, H, W, IC_CO, PSampleOps{}));
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -460,28 +463,30 @@ int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float
 // d loss / d x of the network: the input gradient of initial_conv (the reference's module is differentiable in
 // its input like any nn.Module, diffusion.py:116; not needed by train() or sample(), so only on request).
 // g_x0: channels-last, 64 stored channels; g_x: NCHW (B, cin, H, W).
-int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
-                           int cout_real, hipStream_t st) {
+int tdx_initial_conv_dgrad(const void* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
+                           int cout_real, hipStream_t st, int io16) {
   const int64_t M = (int64_t)B * H * W;
   const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
-  if (cin == 1 && cout_real == 64) fat_to_thin_conv_kernel<1, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
-  else if (cin == 4 && cout_real == 32) fat_to_thin_conv_kernel<4, true><<<grid, 256, 0, st>>>(g_x0, w, nullptr, g_x, B, H, W, cout_real);
-  else return TDX_E_SHAPE;
+  if (!((cin == 1 && cout_real == 64) || (cin == 4 && cout_real == 32))) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cin == 1) fat_to_thin_conv_kernel<1, true, false, T><<<grid, 256, 0, st>>>((const T*)g_x0, w, nullptr, g_x, B, H, W, cout_real, PSampleOps{});
+    else fat_to_thin_conv_kernel<4, true, false, T><<<grid, 256, 0, st>>>((const T*)g_x0, w, nullptr, g_x, B, H, W, cout_real, PSampleOps{}));
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
 // final_conv forward with the reverse-process update fused in (sampling; PSampleOps above)
-int tdx_final_conv_fwd_psample(const float* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
+int tdx_final_conv_fwd_psample(const void* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
                                int cout, float* x, const float* z, const float* coef, const int32_t* t_idx,
-                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st) {
+                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st, int io16) {
   if (!x || !coef || !t_idx) return TDX_E_BADARG;
   const int64_t M = (int64_t)B * H * W;
   const int grid = (int)std::min<int64_t>((M + 15) / 16, 8192);
   const PSampleOps ps{x, z, coef, t_idx, seed, philox, counter_dec};
-  if (cout == 1) fat_to_thin_conv_kernel<1, false, true><<<grid, 256, 0, st>>>(in, w, bias, eps_out, B, H, W, IC_CO, ps);
-  else if (cout == 4) fat_to_thin_conv_kernel<4, false, true><<<grid, 256, 0, st>>>(in, w, bias, eps_out, B, H, W, IC_CO, ps);
-  else return TDX_E_SHAPE;
+  if (cout != 1 && cout != 4) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cout == 1) fat_to_thin_conv_kernel<1, false, true, T><<<grid, 256, 0, st>>>((const T*)in, w, bias, eps_out, B, H, W, IC_CO, ps);
+    else fat_to_thin_conv_kernel<4, false, true, T><<<grid, 256, 0, st>>>((const T*)in, w, bias, eps_out, B, H, W, IC_CO, ps));
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -491,28 +496,28 @@ int tdx_small_conv_wgrad_blocks(int B, int H, int W) {
 }
 int tdx_small_conv_partial_width(void) { return SMALLP_W; }
 
-int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
-                           int B, int H, int W, int cin, int cout_real, hipStream_t st) {
+int tdx_initial_conv_wgrad(const float* x, const void* g, float* partial, float* dw, float* db,
+                           int B, int H, int W, int cin, int cout_real, hipStream_t st, int io16) {
   const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
   if (W < 4) return TDX_E_SHAPE;
-  if (cin == 1 && cout_real == 64)
-    thin_fat_wgrad_kernel<1, false><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, WGRAD_PIX, cout_real);
-  else if (cin == 4 && cout_real == 32)
-    thin_fat_wgrad_kernel<4, false><<<nblk, 256, 0, st>>>(x, g, partial, B, H, W, WGRAD_PIX, cout_real);
-  else return TDX_E_SHAPE;
+  if (!((cin == 1 && cout_real == 64) || (cin == 4 && cout_real == 32))) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cin == 1) thin_fat_wgrad_kernel<1, false, T><<<nblk, 256, 0, st>>>(x, (const T*)g, partial, B, H, W, WGRAD_PIX, cout_real);
+    else thin_fat_wgrad_kernel<4, false, T><<<nblk, 256, 0, st>>>(x, (const T*)g, partial, B, H, W, WGRAD_PIX, cout_real));
   TDX_CHECK_LAUNCH();
   // columns [0, nw) -> dw (contiguous [co][ci][tap]), then cout_real columns -> db
   const int nw = cout_real * cin * 9;
   return reduce_partials2(partial, dw, db, nw, nblk, SMALLP_W, nw + cout_real, st);
 }
 
-int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
-                         int B, int H, int W, int cout, hipStream_t st) {
+int tdx_final_conv_wgrad(const void* in, const float* g_out, float* partial, float* dw, float* db,
+                         int B, int H, int W, int cout, hipStream_t st, int io16) {
   const int nblk = tdx_small_conv_wgrad_blocks(B, H, W);
   if (W < 4) return TDX_E_SHAPE;
-  if (cout == 1) thin_fat_wgrad_kernel<1, true><<<nblk, 256, 0, st>>>(g_out, in, partial, B, H, W, WGRAD_PIX, IC_CO);
-  else if (cout == 4) thin_fat_wgrad_kernel<4, true><<<nblk, 256, 0, st>>>(g_out, in, partial, B, H, W, WGRAD_PIX, IC_CO);
-  else return TDX_E_SHAPE;
+  if (cout != 1 && cout != 4) return TDX_E_SHAPE;
+  TDX_IO_DISPATCH(io16, T,
+    if (cout == 1) thin_fat_wgrad_kernel<1, true, T><<<nblk, 256, 0, st>>>(g_out, (const T*)in, partial, B, H, W, WGRAD_PIX, IC_CO);
+    else thin_fat_wgrad_kernel<4, true, T><<<nblk, 256, 0, st>>>(g_out, (const T*)in, partial, B, H, W, WGRAD_PIX, IC_CO));
   TDX_CHECK_LAUNCH();
   return reduce_partials2(partial, dw, db, cout * 576, nblk, SMALLP_W, cout * 576 + cout, st);
 }

@@ -3,28 +3,28 @@
 #include "common.h"
 
 int tdx_copy_floats(const float* src, float* dst, size_t n, hipStream_t st);
-int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t st);
+int tdx_pixel_sum(const void* g, float* out, int B, int HW, int C, hipStream_t st, int io16 = 0);
 int tdx_reduce_partials(const float* partial, float* out, int nblk, int stride, int count,
                         hipStream_t st);
 // initial_conv: NCHW model input (cin = 1 | 4) -> channels-last, 64 channels stored of which the
 // first cout_real (64 | 32) are real; final_conv: channels-last 64 -> NCHW cout (1 | 4)
-int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                         int W, int cin, int cout_real, hipStream_t st);
+int tdx_initial_conv_fwd(const float* x, const float* w, const float* bias, void* out, int B, int H,
+                         int W, int cin, int cout_real, hipStream_t st, int io16 = 0);
 int tdx_small_conv_wgrad_blocks(int B, int H, int W);
 int tdx_small_conv_partial_width(void);
-int tdx_initial_conv_wgrad(const float* x, const float* g, float* partial, float* dw, float* db,
-                           int B, int H, int W, int cin, int cout_real, hipStream_t st);
-int tdx_initial_conv_dgrad(const float* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
-                           int cout_real, hipStream_t st);
-int tdx_final_conv_fwd(const float* in, const float* w, const float* bias, float* out, int B, int H,
-                       int W, int cout, hipStream_t st);
-int tdx_final_conv_fwd_psample(const float* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
+int tdx_initial_conv_wgrad(const float* x, const void* g, float* partial, float* dw, float* db,
+                           int B, int H, int W, int cin, int cout_real, hipStream_t st, int io16 = 0);
+int tdx_initial_conv_dgrad(const void* g_x0, const float* w, float* g_x, int B, int H, int W, int cin,
+                           int cout_real, hipStream_t st, int io16 = 0);
+int tdx_final_conv_fwd(const void* in, const float* w, const float* bias, float* out, int B, int H,
+                       int W, int cout, hipStream_t st, int io16 = 0);
+int tdx_final_conv_fwd_psample(const void* in, const float* w, const float* bias, float* eps_out, int B, int H, int W,
                                int cout, float* x, const float* z, const float* coef, const int32_t* t_idx,
-                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st);
-int tdx_final_conv_dgrad(const float* g_out, const float* w, float* g_in, int B, int H, int W,
-                         int cout, hipStream_t st);
-int tdx_final_conv_wgrad(const float* in, const float* g_out, float* partial, float* dw, float* db,
-                         int B, int H, int W, int cout, hipStream_t st);
+                               uint64_t seed, int philox, int64_t* counter_dec, hipStream_t st, int io16 = 0);
+int tdx_final_conv_dgrad(const float* g_out, const float* w, void* g_in, int B, int H, int W,
+                         int cout, hipStream_t st, int io16 = 0);
+int tdx_final_conv_wgrad(const void* in, const float* g_out, float* partial, float* dw, float* db,
+                         int B, int H, int W, int cout, hipStream_t st, int io16 = 0);
 // kind 0: raw-t MLP (+ class embedding y); kind 1: sinusoid + 768-d MLP + additive `cond`
 int tdx_time_embed_fwd(int kind, const int64_t* t, const int64_t* y, const float* cond,
                        const float* const* P, float* sin, float* pre, float* emb, float* t1, float* t2,
@@ -76,11 +76,18 @@ int tdx_bn_finalize_moments(const double* mom, int C, const float* gamma, const 
 int tdx_bn_relu_bwd_sync(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
                          const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
                          float* dbeta, float* dbias, float* scratch, int training, tdx_allreduce_fn sync,
-                         void* sync_user, double* mom, tdx_stream_t stream);
+                         void* sync_user, double* mom, tdx_stream_t stream, int io16 = 0);
 extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd_kernel (int64 t from the workspace copy)
 extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
                         float* tf_out, int B, hipStream_t st);
+// bf16 compute mode with bf16 STORAGE of the activation tensors (conv3x3_bf16.hip): io16 = `in` / `out` / `dy` hold bf16
+int tdx_conv3x3_fwd_bf16_io(const void* in, const void* wpk_bf16, const float* bias, void* out, int B, int H, int W,
+                            int cin, int cout, int flags, const float* in_scale, const float* in_shift,
+                            const float* out_scale, const float* out_shift, float* stats_partial, int io16,
+                            tdx_stream_t stream);
+int tdx_conv3x3_wgrad_bf16_io(const void* in, const void* dy, float* dw_slabs, int B, int H, int W, int cin, int cout,
+                              int flags, const float* in_scale, const float* in_shift, int io16, tdx_stream_t stream);
 // sampling tables (time_embed.hip) and the pieces of a table-mode reverse step
 int tdx_time_tables_build(int kind, const float* const* P, int T, int td, float* tab1, float* tab2, float* tab3,
                           float* scratch, hipStream_t st);
@@ -115,6 +122,7 @@ extern int g_tdx_time_stage;
 // unit's BatchNorm backward, and the separate reduction pass is skipped (unet.hip, tdx_unet_backward)
 extern int g_tdx_bnbwd_fused;
 extern int g_tdx_sample_tables;
+extern int g_tdx_bf16_storage;
 extern int g_tdx_sample_fuse;       // bit 0 defer split-K reductions into the resize kernels, 1 pool in the reduction, 2 update in final_conv
 extern int g_tdx_sample_defer_max;
 int tdx_conv3x3_dgrad_bnbwd(const float* in, const float* wpk, float* out, int B, int H, int W, int cin, int cout,
@@ -126,16 +134,22 @@ int tdx_conv3x3_dgrad_bnbwd(const float* in, const float* wpk, float* out, int B
 int tdx_bn_relu_bwd_tail(float* g, const float* y, int64_t rows, int C, const float* scale, const float* shift,
                          const float* save_mean, const float* save_rstd, const float* gamma, float* dgamma,
                          float* dbeta, float* dbias, const float* partial, int nblk, float* coef, int training,
-                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream);
+                         tdx_allreduce_fn sync, void* sync_user, double* mom, tdx_stream_t stream, int io16 = 0);
 // the resize adjoint / max-pool backward that also emit those partial sums for the tensor they write
 // (bn_y .. bn_rstd of the unit whose activation gradient g_in is; partial [*nblk][2][C])
-int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
-                           int g_cstride, int g_coff, const float* bn_y, const float* bn_scale,
+int tdx_bilinear_ac_bwd_bn(const void* g_out, void* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           int g_cstride, int g_coff, const void* bn_y, const float* bn_scale,
                            const float* bn_shift, const float* bn_mean, const float* bn_rstd, float* partial,
-                           int* nblk, tdx_stream_t stream);
-int tdx_maxpool2_ceil_bwd_bn(const float* y, const float* scale, const float* shift, const float* g_out,
-                             const float* skip_grad, float* g_in, int B, int H, int W, int C, const float* bn_mean,
-                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream);
+                           int* nblk, tdx_stream_t stream, int io16 = 0);
+int tdx_maxpool2_ceil_bwd_bn(const void* y, const float* scale, const float* shift, const void* g_out,
+                             const void* skip_grad, void* g_in, int B, int H, int W, int C, const float* bn_mean,
+                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream, int io16 = 0);
+// the fp32 | bf16 forms of the spatial kernels (io16: activation tensors hold bf16, io16.h)
+int tdx_maxpool2_ceil_fwd_t(const void* y, const float* scale, const float* shift, void* out, int B, int H, int W,
+                            int C, int io16, tdx_stream_t stream);
+int tdx_bilinear_ac_fwd_t(const void* in, const float* scale, const float* shift, const float* addend, void* out, int B,
+                          int Hi, int Wi, int Ho, int Wo, int C, int out_cstride, int out_coff, int io16,
+                          tdx_stream_t stream);
 #define TDX_BNBWD_MAX_PRODUCER_BLOCKS 2048   // workgroups of the two spatial producers above
 extern int g_tdx_time_proj_early;
 // inference: both halves of a decoder's concatenated input (resize(a) | resize(b + b_addend)) in one launch
@@ -149,8 +163,8 @@ struct TdxPoolFuse { float* pooled; };
 struct TdxSplitDefer {
   const float* partial; int splits; size_t slab; const float* bias; const float* scale; const float* shift;
 };
-int tdx_bilinear_pair_fwd_ex(const float* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const float* b,
-                             const float* b_addend, int Hb, int Wb, int Cb, float* out, int B, int Ho, int Wo,
-                             hipStream_t st);
+int tdx_bilinear_pair_fwd_ex(const void* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const void* b,
+                             const float* b_addend, int Hb, int Wb, int Cb, void* out, int B, int Ho, int Wo,
+                             hipStream_t st, int io16 = 0);
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
                           int Wb, int Cb, float* out, int B, int Ho, int Wo, hipStream_t st);

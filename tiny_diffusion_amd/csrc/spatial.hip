@@ -4,6 +4,7 @@
 //   bilinear resize, align_corners=True          diffusion.py:102, 135-159
 // and their backward passes (the boundary convolutions initial_conv / final_conv live in edge_conv.hip).
 #include "internal.h"
+#include "io16.h"
 
 __device__ static inline float4 bnrelu4(float4 v, const float4& sc, const float4& sh) {
   v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
@@ -20,7 +21,7 @@ __device__ static inline float4 bnrelu4(float4 v, const float4& sc, const float4
 // over both tensors.  Every thread of these kernels keeps ONE channel quad for its whole life (256 % (C/4) == 0 and
 // its stride is a multiple of 256), so the sums live in registers and meet in LDS once, in a fixed order.
 struct BnBwdOps {
-  const float* y;       // pre-BN output of the unit, same layout as the gradient being written
+  const void* y;        // pre-BN output of the unit, same layout and element type as the gradient being written
   const float* scale; const float* shift; const float* mean; const float* rstd;
   float* partial;       // [gridDim.x][2][C]
 };
@@ -57,9 +58,9 @@ static inline int ew_grid(int64_t n, int block = 256, int cap = 4096) {
 }
 
 // ------------------------------------------------------------------- max-pool
-template <bool BN>
-__global__ void maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, float* __restrict__ out, int B,
+template <bool BN, typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, T* __restrict__ out, int B,
                                    int H, int W, int C) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
   const int64_t n = (int64_t)B * Ho * Wo * c4n;
@@ -82,35 +83,41 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ y, const float* __r
       for (int dw = 0; dw < 2; ++dw) {
         const int ih = 2 * oh + dh, iw = 2 * ow + dw;
         if (ih < H && iw < W) {
-          float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)b * H + ih) * W + iw) * C + c);
+          float4 v = ld4(y + (((int64_t)b * H + ih) * W + iw) * C + c);
           if (BN) v = bnrelu4(v, sc, sh);
           m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y);
           m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
       }
-    *reinterpret_cast<float4*>(out + i * 4) = m;
+    st4(out + i * 4, m);
   }
 }
 
-extern "C" int tdx_maxpool2_ceil_fwd(const float* y, const float* scale, const float* shift,
-                                     float* out, int B, int H, int W, int C, tdx_stream_t stream) {
+// io16: y and out hold bf16 (io16.h); the C-ABI entry is the fp32 form
+int tdx_maxpool2_ceil_fwd_t(const void* y, const float* scale, const float* shift, void* out, int B, int H, int W,
+                            int C, int io16, tdx_stream_t stream) {
   if (!y || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return TDX_E_BADARG;
   if (C % 4) return TDX_E_SHAPE;
   const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-  if (scale) maxpool_fwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, out, B, H, W, C);
-  else maxpool_fwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, out, B, H, W, C);
+  TDX_IO_DISPATCH(io16, T,
+    if (scale) maxpool_fwd_kernel<true, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>((const T*)y, scale, shift, (T*)out, B, H, W, C);
+    else maxpool_fwd_kernel<false, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>((const T*)y, scale, shift, (T*)out, B, H, W, C));
   TDX_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int tdx_maxpool2_ceil_fwd(const float* y, const float* scale, const float* shift,
+                                     float* out, int B, int H, int W, int C, tdx_stream_t stream) {
+  return tdx_maxpool2_ceil_fwd_t(y, scale, shift, out, B, H, W, C, 0, stream);
 }
 
 // One thread owns one 2x2 window (windows do not overlap): route the pooled
 // gradient to the FIRST maximum in scan order (ATen: `val > maxval`), add the
 // skip-path gradient, and write all (up to) four input positions.
-template <bool BN, bool BNP = false>
-__global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, const float* __restrict__ g_out,
-                                   const float* __restrict__ skip, float* __restrict__ g_in, int B,
-                                   int H, int W, int C, BnBwdOps bw = BnBwdOps{}) {
+template <bool BN, bool BNP, typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const T* __restrict__ g_out,
+                                   const T* __restrict__ skip, T* __restrict__ g_in, int B,
+                                   int H, int W, int C, BnBwdOps bw) {
   __shared__ __attribute__((aligned(16))) float red[BNP ? 2048 : 4];
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, c4n = C / 4;
   const int64_t n = (int64_t)B * Ho * Wo * c4n;
@@ -132,7 +139,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
       sc = *reinterpret_cast<const float4*>(scale + c);
       sh = *reinterpret_cast<const float4*>(shift + c);
     }
-    const float4 go = *reinterpret_cast<const float4*>(g_out + i * 4);
+    const float4 go = ld4(g_out + i * 4);
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int arg[4] = {0, 0, 0, 0};
     float4 yraw[4];
@@ -140,7 +147,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
     for (int k = 0; k < 4; ++k) {
       const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
       if (ih < H && iw < W) {
-        float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)b * H + ih) * W + iw) * C + c);
+        float4 v = ld4(y + (((int64_t)b * H + ih) * W + iw) * C + c);
         yraw[k] = v;
         if (BN) v = bnrelu4(v, sc, sh);
         if (v.x > m[0]) { m[0] = v.x; arg[0] = k; }
@@ -154,12 +161,12 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
       const int ih = 2 * oh + (k >> 1), iw = 2 * ow + (k & 1);
       if (ih < H && iw < W) {
         const int64_t off = (((int64_t)b * H + ih) * W + iw) * C + c;
-        float4 r = skip ? *reinterpret_cast<const float4*>(skip + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r = skip ? ld4(skip + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (arg[0] == k) r.x += go.x;
         if (arg[1] == k) r.y += go.y;
         if (arg[2] == k) r.z += go.z;
         if (arg[3] == k) r.w += go.w;
-        *reinterpret_cast<float4*>(g_in + off) = r;
+        st4(g_in + off, r);
         if (BNP) bnbwd_acc(r, yraw[k], sc, sh, mu, rs, s1, s2);
       }
     }
@@ -167,29 +174,35 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __r
   if (BNP) bnbwd_flush(red, s1, s2, C, bw.partial);
 }
 
-extern "C" int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const float* shift,
-                                     const float* g_out, const float* skip_grad, float* g_in, int B,
-                                     int H, int W, int C, tdx_stream_t stream) {
+static int maxpool_bwd_t(const void* y, const float* scale, const float* shift, const void* g_out,
+                         const void* skip_grad, void* g_in, int B, int H, int W, int C, int io16, tdx_stream_t stream) {
   if (!y || !g_out || !g_in || B <= 0 || H <= 0 || W <= 0 || C <= 0) return TDX_E_BADARG;
   if (C % 4) return TDX_E_SHAPE;
   const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-  if (scale) maxpool_bwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
-  else maxpool_bwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C);
+  TDX_IO_DISPATCH(io16, T,
+    if (scale) maxpool_bwd_kernel<true, false, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>((const T*)y, scale, shift, (const T*)g_out, (const T*)skip_grad, (T*)g_in, B, H, W, C, BnBwdOps{});
+    else maxpool_bwd_kernel<false, false, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>((const T*)y, scale, shift, (const T*)g_out, (const T*)skip_grad, (T*)g_in, B, H, W, C, BnBwdOps{}));
   TDX_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int tdx_maxpool2_ceil_bwd(const float* y, const float* scale, const float* shift,
+                                     const float* g_out, const float* skip_grad, float* g_in, int B,
+                                     int H, int W, int C, tdx_stream_t stream) {
+  return maxpool_bwd_t(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, 0, stream);
+}
 
-int tdx_maxpool2_ceil_bwd_bn(const float* y, const float* scale, const float* shift, const float* g_out,
-                             const float* skip_grad, float* g_in, int B, int H, int W, int C, const float* bn_mean,
-                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream) {
+int tdx_maxpool2_ceil_bwd_bn(const void* y, const float* scale, const float* shift, const void* g_out,
+                             const void* skip_grad, void* g_in, int B, int H, int W, int C, const float* bn_mean,
+                             const float* bn_rstd, float* partial, int* nblk, tdx_stream_t stream, int io16) {
   *nblk = 0;
   if (!(g_tdx_bnbwd_fused & 4) || !scale || !partial || C % 4 || C > 1024 || 256 % (C / 4))
-    return tdx_maxpool2_ceil_bwd(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, stream);
+    return maxpool_bwd_t(y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, io16, stream);
   if (!y || !g_out || !g_in || !bn_mean || !bn_rstd || B <= 0 || H <= 0 || W <= 0) return TDX_E_BADARG;
   const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   const int grid = ew_grid(n, 256, TDX_BNBWD_MAX_PRODUCER_BLOCKS);
-  maxpool_bwd_kernel<true, true><<<grid, 256, 0, to_stream(stream)>>>(
-      y, scale, shift, g_out, skip_grad, g_in, B, H, W, C, BnBwdOps{y, scale, shift, bn_mean, bn_rstd, partial});
+  TDX_IO_DISPATCH(io16, T, maxpool_bwd_kernel<true, true, T><<<grid, 256, 0, to_stream(stream)>>>(
+      (const T*)y, scale, shift, (const T*)g_out, (const T*)skip_grad, (T*)g_in, B, H, W, C,
+      BnBwdOps{y, scale, shift, bn_mean, bn_rstd, partial}));
   TDX_CHECK_LAUNCH();
   *nblk = grid;
   return 0;
@@ -212,10 +225,10 @@ __device__ static inline AxisTap axis_tap(int dst, float scale, int n_in) {
   return t;
 }
 
-template <bool BN>
-__global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+template <bool BN, typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ in, const float* __restrict__ scale,
                                     const float* __restrict__ shift,
-                                    const float* __restrict__ addend, float* __restrict__ out, int B,
+                                    const float* __restrict__ addend, T* __restrict__ out, int B,
                                     int Hi, int Wi, int Ho, int Wo, int C, int ocs, int ocoff,
                                     float sch, float scw) {
   const int c4n = C / 4;
@@ -234,9 +247,9 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* _
       sh = *reinterpret_cast<const float4*>(shift + c);
     }
     if (addend) ad = *reinterpret_cast<const float4*>(addend + (int64_t)b * C + c);
-    const float* base = in + (int64_t)b * Hi * Wi * C + c;
+    const T* base = in + (int64_t)b * Hi * Wi * C + c;
     auto ld = [&](int h, int w) {
-      float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)h * Wi + w) * C);
+      float4 v = ld4(base + ((int64_t)h * Wi + w) * C);
       if (BN) v = bnrelu4(v, sc, sh);
       v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
       return v;
@@ -253,7 +266,7 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* _
     }
     LERP(x) LERP(y) LERP(z) LERP(w)
 #undef LERP
-    *reinterpret_cast<float4*>(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + ocoff + c) = o;
+    st4(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + ocoff + c, o);
   }
 }
 
@@ -265,10 +278,11 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ in, const float* _
 // written, which nothing else reads in INFER mode) disappears.  An up-sampled source is touched by ~4 outputs
 // per element, so the sums are formed ~4 times over; the partials of a 16-sample step are L2-resident.
 struct ResizeSrc {
-  const float* in; const float* addend; int Hi, Wi, C; float sch, scw;
+  const void* in; const float* addend; int Hi, Wi, C; float sch, scw;   // in: T elements (fp32 partials when splits > 0)
   int splits; size_t slab; const float* bias; const float* scale; const float* shift;
 };
-__global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __restrict__ out, int B, int Ho,
+template <typename T>
+__global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, T* __restrict__ out, int B, int Ho,
                                          int Wo) {
   const int ocs = A.C + Bs.C, c4n = ocs / 4;
   const int64_t n = (int64_t)B * Ho * Wo * c4n;
@@ -285,7 +299,7 @@ __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __res
     const AxisTap th = axis_tap(oh, S.sch, S.Hi), tw = axis_tap(ow, S.scw, S.Wi);
     float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
     if (S.addend) ad = *reinterpret_cast<const float4*>(S.addend + (int64_t)b * S.C + c);
-    const float* base = S.in + (int64_t)b * S.Hi * S.Wi * S.C + c;
+    const int64_t boff = (int64_t)b * S.Hi * S.Wi * S.C + c;
     float4 dbv = make_float4(0.f, 0.f, 0.f, 0.f), dsc = dbv, dsh = dbv;
     if (S.splits > 0) {
       if (S.bias) dbv = *reinterpret_cast<const float4*>(S.bias + c);
@@ -293,9 +307,10 @@ __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __res
       dsh = *reinterpret_cast<const float4*>(S.shift + c);
     }
     auto ld = [&](int h, int w) {
-      const float* q = base + ((int64_t)h * S.Wi + w) * S.C;
+      const int64_t qo = boff + ((int64_t)h * S.Wi + w) * S.C;
       float4 v;
-      if (S.splits > 0) {   // deferred split-K source: the reduction epilogue of splitk_reduce_kernel<true>, on load
+      if (S.splits > 0) {   // deferred split-K source (fp32 partials): the epilogue of splitk_reduce_kernel<true>, on load
+        const float* q = static_cast<const float*>(S.in) + qo;
         v = dbv;
         for (int sp = 0; sp < S.splits; ++sp) {
           const float4 t = *reinterpret_cast<const float4*>(q + (size_t)sp * S.slab);
@@ -303,7 +318,7 @@ __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __res
         }
         v = bnrelu4(v, dsc, dsh);
       } else {
-        v = *reinterpret_cast<const float4*>(q);
+        v = ld4(static_cast<const T*>(S.in) + qo);
       }
       v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
       return v;
@@ -319,7 +334,7 @@ __global__ void bilinear_pair_fwd_kernel(ResizeSrc A, ResizeSrc Bs, float* __res
     }
     LERP(x) LERP(y) LERP(z) LERP(w)
 #undef LERP
-    *reinterpret_cast<float4*>(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + oc) = o;
+    st4(out + (((int64_t)b * Ho + oh) * Wo + ow) * ocs + oc, o);
   }
 }
 
@@ -327,22 +342,28 @@ static inline float ac_scale(int n_in, int n_out) {
   return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
 }
 
-extern "C" int tdx_bilinear_ac_fwd(const float* in, const float* scale, const float* shift,
-                                   const float* addend, float* out, int B, int Hi, int Wi, int Ho,
-                                   int Wo, int C, int out_cstride, int out_coff,
-                                   tdx_stream_t stream) {
+int tdx_bilinear_ac_fwd_t(const void* in, const float* scale, const float* shift, const float* addend, void* out, int B,
+                          int Hi, int Wi, int Ho, int Wo, int C, int out_cstride, int out_coff, int io16,
+                          tdx_stream_t stream) {
   if (!in || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return TDX_E_BADARG;
   if (C % 4 || out_cstride % 4 || out_coff % 4 || out_coff + C > out_cstride) return TDX_E_SHAPE;
   const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
   const float sch = ac_scale(Hi, Ho), scw = ac_scale(Wi, Wo);
-  if (scale)
-    bilinear_fwd_kernel<true><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
-        in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
-  else
-    bilinear_fwd_kernel<false><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
-        in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
+  TDX_IO_DISPATCH(io16, T,
+    if (scale)
+      bilinear_fwd_kernel<true, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+          (const T*)in, scale, shift, addend, (T*)out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw);
+    else
+      bilinear_fwd_kernel<false, T><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+          (const T*)in, scale, shift, addend, (T*)out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, sch, scw));
   TDX_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int tdx_bilinear_ac_fwd(const float* in, const float* scale, const float* shift,
+                                   const float* addend, float* out, int B, int Hi, int Wi, int Ho,
+                                   int Wo, int C, int out_cstride, int out_coff,
+                                   tdx_stream_t stream) {
+  return tdx_bilinear_ac_fwd_t(in, scale, shift, addend, out, B, Hi, Wi, Ho, Wo, C, out_cstride, out_coff, 0, stream);
 }
 
 int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b, const float* b_addend, int Hb,
@@ -352,19 +373,19 @@ int tdx_bilinear_pair_fwd(const float* a, int Ha, int Wa, int Ca, const float* b
 
 // the same with source A optionally a deferred split-K result (a_defer != null: `a` is ignored) and source B optional
 // (Cb == 0: a plain resize of A into `out`)
-int tdx_bilinear_pair_fwd_ex(const float* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const float* b,
-                             const float* b_addend, int Hb, int Wb, int Cb, float* out, int B, int Ho, int Wo,
-                             hipStream_t st) {
+int tdx_bilinear_pair_fwd_ex(const void* a, const TdxSplitDefer* a_defer, int Ha, int Wa, int Ca, const void* b,
+                             const float* b_addend, int Hb, int Wb, int Cb, void* out, int B, int Ho, int Wo,
+                             hipStream_t st, int io16) {
   const bool deferred = a_defer && a_defer->splits > 0;
   if ((!a && !deferred) || (!b && Cb) || !out || Ca % 4 || Cb % 4 || Ca <= 0 || Cb < 0) return TDX_E_BADARG;
   if (deferred && (!a_defer->partial || !a_defer->scale || !a_defer->shift)) return TDX_E_BADARG;
-  ResizeSrc A{deferred ? a_defer->partial : a, nullptr, Ha, Wa, Ca, ac_scale(Ha, Ho), ac_scale(Wa, Wo),
+  ResizeSrc A{deferred ? static_cast<const void*>(a_defer->partial) : a, nullptr, Ha, Wa, Ca, ac_scale(Ha, Ho), ac_scale(Wa, Wo),
               deferred ? a_defer->splits : 0, deferred ? a_defer->slab : 0, deferred ? a_defer->bias : nullptr,
               deferred ? a_defer->scale : nullptr, deferred ? a_defer->shift : nullptr};
   ResizeSrc Bs{b, b_addend, Cb ? Hb : 1, Cb ? Wb : 1, Cb, Cb ? ac_scale(Hb, Ho) : 0.f, Cb ? ac_scale(Wb, Wo) : 0.f,
                0, 0, nullptr, nullptr, nullptr};
   const int64_t n = (int64_t)B * Ho * Wo * ((Ca + Cb) / 4);
-  bilinear_pair_fwd_kernel<<<ew_grid(n), 256, 0, st>>>(A, Bs, out, B, Ho, Wo);
+  TDX_IO_DISPATCH(io16, T, bilinear_pair_fwd_kernel<T><<<ew_grid(n), 256, 0, st>>>(A, Bs, (T*)out, B, Ho, Wo));
   TDX_CHECK_LAUNCH();
   return 0;
 }
@@ -398,7 +419,8 @@ __device__ static inline void axis_adjoint(int i, float scale, int n_in, int n_o
   }
 }
 
-__global__ void bilinear_bwd_kernel(const float* __restrict__ g_out, float* __restrict__ g_in, int B,
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ g_out, T* __restrict__ g_in, int B,
                                     int Hi, int Wi, int Ho, int Wo, int C, int gcs, int gcoff,
                                     float sch, float scw) {
   const int c4n = C / 4;
@@ -421,14 +443,13 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ g_out, float* __re
 #pragma unroll
       for (int d = 0; d < BIL_MAXC; ++d) {
         if (ww[d] == 0.f) continue;
-        const float4 g = *reinterpret_cast<const float4*>(
-            g_out + (((int64_t)b * Ho + hlo + a) * Wo + wlo + d) * gcs + gcoff + c);
+        const float4 g = ld4(g_out + (((int64_t)b * Ho + hlo + a) * Wo + wlo + d) * gcs + gcoff + c);
         const float w = wh[a] * ww[d];
         acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y);
         acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
       }
     }
-    *reinterpret_cast<float4*>(g_in + i * 4) = acc;
+    st4(g_in + i * 4, acc);
   }
 }
 
@@ -459,9 +480,9 @@ __device__ static inline void axis_window(int i, float scale, int n_in, int n_ou
   n_out_w = last >= 0 ? last - first + 1 : 0;
 }
 
-template <bool BNP>
+template <bool BNP, typename T>
 __global__ void __launch_bounds__(256)
-bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_in, int rows,
+bilinear_bwd_rows_kernel(const T* __restrict__ g_out, T* __restrict__ g_in, int rows,
                          int Hi, int Wi, int Ho, int Wo, int C, int gcs, int gcoff, float sch,
                          float scw, BnBwdOps bw) {
   __shared__ float s_ww[BIL_ROW_MAXW][BIL_MAXC], s_wh[BIL_ROW_MAXW][BIL_MAXC];
@@ -484,8 +505,8 @@ bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int b = r / Hi, ih = r - b * Hi;
     const int hlo = s_hlo[ih], hn = s_hn[ih];
-    const float* grow = g_out + ((int64_t)b * Ho + hlo) * Wo * gcs + gcoff;
-    float* orow = g_in + (int64_t)r * per_row * 4;
+    const T* grow = g_out + ((int64_t)b * Ho + hlo) * Wo * gcs + gcoff;
+    T* orow = g_in + (int64_t)r * per_row * 4;
     for (int j = tid; j < per_row; j += 256) {
       const int iw = j / c4n, c = (j - iw * c4n) * 4;
       const int wlo = s_wlo[iw], wn = s_wn[iw];
@@ -500,11 +521,11 @@ bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_
         for (int a = 0; a < hn; ++a) {
           const float wa = s_wh[ih][a];
           if (wa == 0.f) continue;
-          const float* gp = grow + ((int64_t)a * Wo + wlo) * gcs + c;
+          const T* gp = grow + ((int64_t)a * Wo + wlo) * gcs + c;
           float4 g[BIL_BATCH];
 #pragma unroll
           for (int d = 0; d < BIL_BATCH; ++d)
-            g[d] = d < wn ? *reinterpret_cast<const float4*>(gp + (int64_t)d * gcs) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[d] = d < wn ? ld4(gp + (int64_t)d * gcs) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int d = 0; d < BIL_BATCH; ++d) {
             if (wd[d] == 0.f) continue;
@@ -517,20 +538,20 @@ bilinear_bwd_rows_kernel(const float* __restrict__ g_out, float* __restrict__ g_
         for (int a = 0; a < hn; ++a) {
           const float wa = s_wh[ih][a];
           if (wa == 0.f) continue;
-          const float* gp = grow + ((int64_t)a * Wo + wlo) * gcs + c;
+          const T* gp = grow + ((int64_t)a * Wo + wlo) * gcs + c;
           for (int d = 0; d < wn; ++d) {
             const float wd = s_ww[iw][d];
             if (wd == 0.f) continue;
-            const float4 g = *reinterpret_cast<const float4*>(gp + (int64_t)d * gcs);
+            const float4 g = ld4(gp + (int64_t)d * gcs);
             const float w = wa * wd;
             acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y);
             acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
           }
         }
       }
-      *reinterpret_cast<float4*>(orow + (int64_t)j * 4) = acc;
+      st4(orow + (int64_t)j * 4, acc);
       if (BNP) {
-        const float4 yv = *reinterpret_cast<const float4*>(bw.y + (int64_t)r * per_row * 4 + (int64_t)j * 4);
+        const float4 yv = ld4(static_cast<const T*>(bw.y) + (int64_t)r * per_row * 4 + (int64_t)j * 4);
         bnbwd_acc(acc, yv, bsc, bsh, bmu, brs, s1, s2);
       }
     }
@@ -552,33 +573,37 @@ static bool adjoint_window_ok(int n_in, int n_out) {
   return true;
 }
 
-extern "C" int tdx_bilinear_ac_bwd(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho,
-                                   int Wo, int C, int g_cstride, int g_coff, tdx_stream_t stream) {
+static int bilinear_ac_bwd_t(const void* g_out, void* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C, int g_cstride,
+                             int g_coff, int io16, tdx_stream_t stream) {
   if (!g_out || !g_in || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return TDX_E_BADARG;
   if (C % 4 || g_cstride % 4 || g_coff % 4 || g_coff + C > g_cstride) return TDX_E_SHAPE;
   if (!adjoint_window_ok(Hi, Ho) || !adjoint_window_ok(Wi, Wo)) return TDX_E_SHAPE;
   const int64_t n = (int64_t)B * Hi * Wi * (C / 4);
   if (Wi <= BIL_ROW_MAXW && Hi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30)) {
     const int rows = B * Hi;
-    bilinear_bwd_rows_kernel<false><<<rows < 16384 ? rows : 16384, 256, 0, to_stream(stream)>>>(
-        g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo), BnBwdOps{});
+    TDX_IO_DISPATCH(io16, T, bilinear_bwd_rows_kernel<false, T><<<rows < 16384 ? rows : 16384, 256, 0, to_stream(stream)>>>(
+        (const T*)g_out, (T*)g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo), BnBwdOps{}));
     TDX_CHECK_LAUNCH();
     return 0;
   }
-  bilinear_bwd_kernel<<<ew_grid(n), 256, 0, to_stream(stream)>>>(
-      g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo));
+  TDX_IO_DISPATCH(io16, T, bilinear_bwd_kernel<T><<<ew_grid(n), 256, 0, to_stream(stream)>>>(
+      (const T*)g_out, (T*)g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo)));
   TDX_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int tdx_bilinear_ac_bwd(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho,
+                                   int Wo, int C, int g_cstride, int g_coff, tdx_stream_t stream) {
+  return bilinear_ac_bwd_t(g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, 0, stream);
+}
 
-int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
-                           int g_cstride, int g_coff, const float* bn_y, const float* bn_scale,
+int tdx_bilinear_ac_bwd_bn(const void* g_out, void* g_in, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           int g_cstride, int g_coff, const void* bn_y, const float* bn_scale,
                            const float* bn_shift, const float* bn_mean, const float* bn_rstd, float* partial,
-                           int* nblk, tdx_stream_t stream) {
+                           int* nblk, tdx_stream_t stream, int io16) {
   *nblk = 0;
   const bool rows_form = Wi <= BIL_ROW_MAXW && Hi <= BIL_ROW_MAXW && (int64_t)B * Hi < (1 << 30);
   if (!(g_tdx_bnbwd_fused & 2) || !bn_y || !partial || !rows_form || C % 4 || C > 1024 || 256 % (C / 4))
-    return tdx_bilinear_ac_bwd(g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, stream);
+    return bilinear_ac_bwd_t(g_out, g_in, B, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, io16, stream);
   if (!g_out || !g_in || !bn_scale || !bn_shift || !bn_mean || !bn_rstd || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 ||
       Wo <= 0)
     return TDX_E_BADARG;
@@ -586,9 +611,9 @@ int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int W
   if (!adjoint_window_ok(Hi, Ho) || !adjoint_window_ok(Wi, Wo)) return TDX_E_SHAPE;
   const int rows = B * Hi;
   const int grid = rows < TDX_BNBWD_MAX_PRODUCER_BLOCKS ? rows : TDX_BNBWD_MAX_PRODUCER_BLOCKS;
-  bilinear_bwd_rows_kernel<true><<<grid, 256, 0, to_stream(stream)>>>(
-      g_out, g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo),
-      BnBwdOps{bn_y, bn_scale, bn_shift, bn_mean, bn_rstd, partial});
+  TDX_IO_DISPATCH(io16, T, bilinear_bwd_rows_kernel<true, T><<<grid, 256, 0, to_stream(stream)>>>(
+      (const T*)g_out, (T*)g_in, rows, Hi, Wi, Ho, Wo, C, g_cstride, g_coff, ac_scale(Hi, Ho), ac_scale(Wi, Wo),
+      BnBwdOps{bn_y, bn_scale, bn_shift, bn_mean, bn_rstd, partial}));
   TDX_CHECK_LAUNCH();
   *nblk = grid;
   return 0;
@@ -596,14 +621,15 @@ int tdx_bilinear_ac_bwd_bn(const float* g_out, float* g_in, int B, int Hi, int W
 
 // ------------------------------------------------- per-(n,c) sum over pixels
 // out[n][c] = sum_{h,w} g[n][h][w][c]   (gradient of the broadcast time/class add)
+template <typename T>
 __global__ void __launch_bounds__(256)
-pixel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int HW, int C) {
+pixel_sum_kernel(const T* __restrict__ g, float* __restrict__ out, int HW, int C) {
   extern __shared__ float red[];  // [rgroups][C]
   const int c4n = C / 4, col = threadIdx.x % c4n, rg = threadIdx.x / c4n, rgroups = 256 / c4n;
-  const float* base = g + (int64_t)blockIdx.x * HW * C + col * 4;
+  const T* base = g + (int64_t)blockIdx.x * HW * C + col * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int p = rg; p < HW; p += rgroups) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)p * C);
+    const float4 v = ld4(base + (int64_t)p * C);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   *reinterpret_cast<float4*>(red + rg * C + col * 4) = s;
@@ -615,10 +641,10 @@ pixel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int HW, i
   }
 }
 
-int tdx_pixel_sum(const float* g, float* out, int B, int HW, int C, hipStream_t st) {
+int tdx_pixel_sum(const void* g, float* out, int B, int HW, int C, hipStream_t st, int io16) {
   if (C % 4 || C > 1024 || 256 % (C / 4)) return TDX_E_SHAPE;
   const int rgroups = 256 / (C / 4);
-  pixel_sum_kernel<<<B, 256, (size_t)rgroups * C * sizeof(float), st>>>(g, out, HW, C);
+  TDX_IO_DISPATCH(io16, T, pixel_sum_kernel<T><<<B, 256, (size_t)rgroups * C * sizeof(float), st>>>((const T*)g, out, HW, C));
   TDX_CHECK_LAUNCH();
   return 0;
 }

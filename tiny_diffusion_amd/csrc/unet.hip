@@ -164,6 +164,7 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+int g_tdx_bf16_storage = 1;     // knob "bf16_storage": plans switched to bf16 afterwards keep their activation tensors in bf16 too
 // Sampling (INFER forward) launch fusions, knob "sample_fuse": bit 0 a split-K result consumed only by a resize is left
 // unreduced and summed by that resize on load (splits <= "sample_defer_max"), bit 1 the reduction of units 3 / 5 also
 // does the max-pool that follows, bit 2 final_conv applies the reverse-process update in its epilogue.  Measured at
@@ -206,6 +207,7 @@ struct tdx_unet {
   // set by tdx_unet_eval_step around its forward: final_conv applies the reverse-process update in its epilogue
   struct { float* x; const float* z; const float* coef; const int32_t* t_idx; uint64_t seed; int philox; int64_t* counter_dec; } ps;
   int precision, saved_precision;  // TDX_PREC_*: of the next forward / of the saved forward
+  int io16, saved_io16;            // bf16 mode: activation tensors in the workspace hold bf16 (io16.h); of the next / saved forward
   tdx_allreduce_fn bn_sync;        // synchronised BatchNorm: all-reduce callback (null: rank-local statistics)
   void* bn_sync_user;
   double* bn_sync_buf;
@@ -294,6 +296,7 @@ extern "C" int tdx_unet_create_full(tdx_unet** out, int max_batch, int kind, int
   u->ps = {};
   u->precision = TDX_PREC_F32;
   u->saved_precision = TDX_PREC_F32;
+  u->io16 = u->saved_io16 = 0;
   u->bn_sync = nullptr;
   u->bn_sync_user = nullptr;
   u->bn_sync_buf = nullptr;
@@ -367,6 +370,8 @@ extern "C" int tdx_unet_set_precision(tdx_unet* u, int precision) {
   if (!u->spec) return precision == TDX_PREC_F32 ? 0 : TDX_E_SHAPE;  // the latent MLP has no bf16 path
   if (precision != u->precision) u->packed = false;                 // INFER packs are per precision
   u->precision = precision;
+  // bf16 mode = bf16 MFMA operands AND bf16 activation tensors in HBM (round 3; knob "bf16_storage" = 0 keeps fp32 tensors)
+  u->io16 = precision == TDX_PREC_BF16 && g_tdx_bf16_storage ? 1 : 0;
   return 0;
 }
 
@@ -582,6 +587,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
   const float* cond_emb = u->kind == 1 ? static_cast<const float*>(cond) : nullptr;
 
   const bool bf16 = u->precision == TDX_PREC_BF16;
+  const int io16 = bf16 ? u->io16 : 0;
   if (!infer) RC(pack_impl(u, params, nullptr, stream, true));  // weights change every step
   else if (!u->packed) RC(pack_impl(u, params, buffers, stream));
   if (!infer) {
@@ -611,7 +617,7 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     RC(tdx_time_embed_fwd(u->kind, t, labels, cond_emb, P, ws + L.sin, ws + L.pre, ws + L.emb, ws + L.tp[0],
                           ws + L.tp[1], ws + L.tp[2], B, tst, S.time_dim));
   RC(tdx_initial_conv_fwd(x, P[TDX_P_INIT_W], P[TDX_P_INIT_B], ws + L.x0, B, S.hw0, S.hw0, S.in_ch,
-                          S.x0_real, st));
+                          S.x0_real, st, io16));
 
   // scale/shift of unit i as seen by its consumers (null in INFER mode: already applied)
   auto sc = [&](int i) -> const float* { return infer ? nullptr : ws + L.ss[i]; };
@@ -650,12 +656,12 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       const int64_t M = (int64_t)B * d.hw * d.hw;
       if (infer) {
         const float* iss = u->infer_ss + u->iss_off[i];
-        return tdx_conv3x3_fwd_bf16(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, nullptr,
-                                    nullptr, iss, iss + d.cout, nullptr, stream);
+        return tdx_conv3x3_fwd_bf16_io(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, nullptr,
+                                       nullptr, iss, iss + d.cout, nullptr, io16, stream);
       }
       const int fl = (d.in_bn ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
-      RC(tdx_conv3x3_fwd_bf16(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, d.in_bn ? sc(i - 1) : nullptr,
-                              d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, stream));
+      RC(tdx_conv3x3_fwd_bf16_io(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, d.in_bn ? sc(i - 1) : nullptr,
+                                 d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, io16, stream));
       const int rows = tdx_conv3x3_bf16_stat_tile_rows();
       RC(finalize_bn(i, cdiv(M, rows), rows, M));
       return 0;
@@ -701,14 +707,14 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
       const int c_up = S.units[kd == 0 ? 6 : 6 + 2 * kd].cout;
       TDX_HIP(hipEventRecord(u->ev_s2_fork[k], st));
       TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_s2_fork[k], 0));
-      RC(tdx_bilinear_ac_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.tp[k], ws + L.cat[kd], B, S.enc_hw[k],
-                             S.enc_hw[k], dd.hw, dd.hw, S.skip_ch[k], dd.cin, c_up,
-                             reinterpret_cast<tdx_stream_t>(u->side2)));
+      RC(tdx_bilinear_ac_fwd_t(ws + L.Y[ub], sc(ub), sh(ub), ws + L.tp[k], ws + L.cat[kd], B, S.enc_hw[k],
+                               S.enc_hw[k], dd.hw, dd.hw, S.skip_ch[k], dd.cin, c_up, io16,
+                               reinterpret_cast<tdx_stream_t>(u->side2)));
       TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
     }
     if (!pf.pooled)   // (null also when the convolution was not split: its reduction could not do the pooling)
-      RC(tdx_maxpool2_ceil_fwd(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
-                               S.skip_ch[k], stream));
+      RC(tdx_maxpool2_ceil_fwd_t(ws + L.Y[ub], sc(ub), sh(ub), ws + L.ep[k], B, S.enc_hw[k], S.enc_hw[k],
+                                 S.skip_ch[k], io16, stream));
   }
   const bool defer_ok = infer && !bf16 && (g_tdx_sample_fuse & 1);
   TdxSplitDefer dfr{};   // the deferred result of the unit about to be resized (6, 8, 10, then 12)
@@ -724,11 +730,11 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     const int hw = da.hw, c_up = dp.cout, c_skip = S.skip_ch[skip_k];
     if (infer) {  // both halves in one launch (post-activation tensors: nothing to apply on load)
       RC(tdx_bilinear_pair_fwd_ex(ws + L.Y[prev], &dfr, dp.hw, dp.hw, c_up, ws + L.Y[skip_u], ws + L.tp[skip_k],
-                                  S.enc_hw[skip_k], S.enc_hw[skip_k], c_skip, ws + L.cat[k], B, hw, hw, st));
+                                  S.enc_hw[skip_k], S.enc_hw[skip_k], c_skip, ws + L.cat[k], B, hw, hw, st, io16));
       dfr = TdxSplitDefer{};
     } else {
-      RC(tdx_bilinear_ac_fwd(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
-                             c_up, da.cin, 0, stream));
+      RC(tdx_bilinear_ac_fwd_t(ws + L.Y[prev], sc(prev), sh(prev), nullptr, ws + L.cat[k], B, dp.hw, dp.hw, hw, hw,
+                               c_up, da.cin, 0, io16, stream));
       TDX_HIP(hipStreamWaitEvent(st, u->ev_s2_done[skip_k], 0));  // skip half: written during the encoder
     }
     RC(run_unit(ua, ws + L.cat[k]));
@@ -739,18 +745,19 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     RC(tdx_bilinear_pair_fwd_ex(nullptr, &dfr, S.dec_hw[2], S.dec_hw[2], 64, nullptr, nullptr, 0, 0, 0, ws + L.d1a, B,
                                 S.out_hw, S.out_hw, st));
   else
-    RC(tdx_bilinear_ac_fwd(ws + L.Y[12], sc(12), sh(12), nullptr, ws + L.d1a, B, S.dec_hw[2], S.dec_hw[2],
-                           S.out_hw, S.out_hw, 64, 64, 0, stream));
+    RC(tdx_bilinear_ac_fwd_t(ws + L.Y[12], sc(12), sh(12), nullptr, ws + L.d1a, B, S.dec_hw[2], S.dec_hw[2],
+                             S.out_hw, S.out_hw, 64, 64, 0, io16, stream));
   if (infer && u->ps.x)
     RC(tdx_final_conv_fwd_psample(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch,
                                   u->ps.x, u->ps.z, u->ps.coef, u->ps.t_idx, u->ps.seed, u->ps.philox, u->ps.counter_dec,
-                                  st));
+                                  st, io16));
   else
-    RC(tdx_final_conv_fwd(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch, st));
+    RC(tdx_final_conv_fwd(ws + L.d1a, P[TDX_P_FINAL_W], P[TDX_P_FINAL_B], out, B, S.out_hw, S.out_hw, S.in_ch, st, io16));
 
   u->saved_batch = infer ? 0 : B;
   u->saved_mode = mode;
   u->saved_precision = u->precision;
+  u->saved_io16 = io16;
   return 0;
 }
 
@@ -780,6 +787,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
   const int training = u->saved_mode == TDX_MODE_TRAIN ? 1 : 0;
   if (u->precision != u->saved_precision) return TDX_E_STATE;  // backward in the precision of its forward
   const bool bf16 = u->saved_precision == TDX_PREC_BF16;
+  const int io16 = u->saved_io16;
   // Activation gradients rotate through FOUR buffers, handed out least-recently-used: the weight
   // gradient of unit u (side stream) keeps reading dy(u) while the main stream is already two
   // units further down, so the two streams are coupled loosely - the side stream works through
@@ -852,12 +860,12 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
                               P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 3],
                               G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, u->bw_nblk,
                               ws + L.bnscr + (size_t)u->bw_nblk * 2 * d.cout, training,
-                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
+                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream, io16));
     } else {
       RC(tdx_bn_relu_bwd_sync(g, ws + L.Y[i], rows, d.cout, ss, ss + d.cout, ss + 2 * d.cout,
                               ss + 3 * d.cout, P[TDX_P_UNIT0 + 4 * i + 2], G[TDX_P_UNIT0 + 4 * i + 2],
                               G[TDX_P_UNIT0 + 4 * i + 3], G[TDX_P_UNIT0 + 4 * i + 1], ws + L.bnscr, training,
-                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream));
+                              training ? u->bn_sync : nullptr, u->bn_sync_user, u->bn_sync_buf, stream, io16));
     }
     u->bw_unit = -1;
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
@@ -881,8 +889,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       u->red_pending[i + 2] = false;
     }
     if (bf16)
-      RC(tdx_conv3x3_wgrad_bf16(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc,
-                                ish, reinterpret_cast<tdx_stream_t>(wst)));
+      RC(tdx_conv3x3_wgrad_bf16_io(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc,
+                                   ish, io16, reinterpret_cast<tdx_stream_t>(wst)));
     else
       RC(tdx_conv3x3_wgrad(in, g, slab, B, d.hw, d.hw, d.cin, d.cout, bn_on_load ? TDX_CONV_IN_BNRELU : 0, isc, ish,
                            reinterpret_cast<tdx_stream_t>(wst)));
@@ -906,8 +914,8 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     float* g_in;
     RC(acquire(g, nullptr, &g_in));
     if (bf16)
-      RC(tdx_conv3x3_fwd_bf16(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, stream));
+      RC(tdx_conv3x3_fwd_bf16_io(g, u->wpack + u->wd_off[i], nullptr, g_in, B, d.hw, d.hw, d.cout, d.cin, 0, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, io16, stream));
     else if (d.in_bn) {
       // g_in is dL/d(activation) of unit i-1 (same resolution, no pool / resize in between): its BatchNorm backward
       // comes next, and this launch's epilogue leaves that unit's partial sums behind (nblk = 0: not on this path)
@@ -924,7 +932,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     return 0;
   };
   // the BatchNorm operands of unit i for a producer of its activation gradient (tdx_*_bwd_bn)
-  auto bw_y = [&](int i) -> const float* { return bf16 ? nullptr : ws + L.Y[i]; };   // null: producer stays unfused
+  auto bw_y = [&](int i) -> const float* { return ws + L.Y[i]; };
   auto plain_unit_bwd = [&](int i, const float* in) -> int {
     float* g_in;
     RC(unit_bwd(i, in, &g_in));
@@ -954,10 +962,14 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     // skip branch (needed only when the encoder is reached): third stream
     TDX_HIP(hipEventRecord(u->ev_s2_fork[k], st));
     TDX_HIP(hipStreamWaitEvent(u->side2, u->ev_s2_fork[k], 0));
-    RC(tdx_bilinear_ac_bwd(gcat, ws + L.GS[skip_k], B, S.enc_hw[skip_k], S.enc_hw[skip_k], da.hw, da.hw,
-                           c_skip, da.cin, c_up, reinterpret_cast<tdx_stream_t>(u->side2)));
+    {
+      int unused = 0;   // (no BatchNorm follows the skip branch: the plain adjoint, in the storage type)
+      RC(tdx_bilinear_ac_bwd_bn(gcat, ws + L.GS[skip_k], B, S.enc_hw[skip_k], S.enc_hw[skip_k], da.hw, da.hw, c_skip,
+                                da.cin, c_up, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &unused,
+                                reinterpret_cast<tdx_stream_t>(u->side2), io16));
+    }
     RC(tdx_pixel_sum(ws + L.GS[skip_k], ws + L.gtp[skip_k], B, S.enc_hw[skip_k] * S.enc_hw[skip_k], c_skip,
-                     u->side2));
+                     u->side2, io16));
     TDX_HIP(hipEventRecord(u->ev_s2_done[k], u->side2));
     // this projection's weight gradient and its share of g(emb) as soon as its pixel sum exists (levels
     // arrive in the order time_proj1, 2, 3 = the summation order of tdx_time_embed_bwd): six of the
@@ -977,7 +989,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       const float* pss = ws + L.ss[prev];
       int nblk = 0;
       RC(tdx_bilinear_ac_bwd_bn(gcat, gup, B, dp.hw, dp.hw, da.hw, da.hw, c_up, da.cin, 0, bw_y(prev), pss, pss + c_up,
-                                pss + 2 * c_up, pss + 3 * c_up, ws + L.bnscr, &nblk, stream));
+                                pss + 2 * c_up, pss + 3 * c_up, ws + L.bnscr, &nblk, stream, io16));
       if (nblk > 0) { u->bw_unit = prev; u->bw_nblk = nblk; }
     }
     touch(gcat);
@@ -1015,7 +1027,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       int nblk = 0;
       RC(tdx_maxpool2_ceil_bwd_bn(ws + L.Y[ub], ssc(ub), ssh(ub), gpool, ws + L.GS[k], gnew, B, S.enc_hw[k],
                                   S.enc_hw[k], cu, ws + L.ss[ub] + 2 * cu, ws + L.ss[ub] + 3 * cu,
-                                  bf16 ? nullptr : ws + L.bnscr, &nblk, stream));
+                                  ws + L.bnscr, &nblk, stream, io16));
       if (nblk > 0) { u->bw_unit = ub; u->bw_nblk = nblk; }
     }
     touch(gpool);
@@ -1029,11 +1041,11 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
         TDX_HIP(hipEventRecord(u->ev_fork, st));  // d_out is ready on the main stream
         TDX_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
         RC(tdx_final_conv_wgrad(ws + L.d1a, d_out, ws + L.smallp2, G[TDX_P_FINAL_W], G[TDX_P_FINAL_B], B,
-                                S.out_hw, S.out_hw, S.in_ch, u->side));
+                                S.out_hw, S.out_hw, S.in_ch, u->side, io16));
         {
           float *gd1a, *g12;
           RC(acquire(nullptr, nullptr, &gd1a));
-          RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], gd1a, B, S.out_hw, S.out_hw, S.in_ch, st));
+          RC(tdx_final_conv_dgrad(d_out, P[TDX_P_FINAL_W], gd1a, B, S.out_hw, S.out_hw, S.in_ch, st, io16));
           if (S.dec_hw[2] == S.out_hw) {  // the output resize is the identity (LAION network): so is its adjoint
             g_next = gd1a;
           } else {
@@ -1041,7 +1053,7 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
             const float* pss = ws + L.ss[12];
             int nblk = 0;
             RC(tdx_bilinear_ac_bwd_bn(gd1a, g12, B, S.dec_hw[2], S.dec_hw[2], S.out_hw, S.out_hw, 64, 64, 0, bw_y(12), pss,
-                                      pss + 64, pss + 128, pss + 192, ws + L.bnscr, &nblk, stream));
+                                      pss + 64, pss + 128, pss + 192, ws + L.bnscr, &nblk, stream, io16));
             if (nblk > 0) { u->bw_unit = 12; u->bw_nblk = nblk; }
             g_next = g12;
           }
@@ -1066,9 +1078,9 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
       case 14:
         if (g_tdx_time_stage != 6) RC(time_path_bwd(st));
         RC(tdx_initial_conv_wgrad(ws + L.x, g_next, ws + L.smallp, G[TDX_P_INIT_W], G[TDX_P_INIT_B], B, S.hw0,
-                                  S.hw0, S.in_ch, S.x0_real, st));
+                                  S.hw0, S.in_ch, S.x0_real, st, io16));
         if (u->g_x) {   // d loss / d x, on request only (tdx_unet_request_input_grad)
-          RC(tdx_initial_conv_dgrad(g_next, P[TDX_P_INIT_W], u->g_x, B, S.hw0, S.hw0, S.in_ch, S.x0_real, st));
+          RC(tdx_initial_conv_dgrad(g_next, P[TDX_P_INIT_W], u->g_x, B, S.hw0, S.hw0, S.in_ch, S.x0_real, st, io16));
           u->g_x = nullptr;
         }
         break;

@@ -10,6 +10,9 @@ from tiny_diffusion_amd.train import TrainStep
 which = sys.argv[1] if len(sys.argv) > 1 else "mnist"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dt = torch.float32 if os.environ.get("TDX_FP32") else torch.bfloat16
+if os.environ.get("TDX_BF16_STORAGE") is not None:   # 0: bf16 MFMA operands only, fp32 tensors (the round-2 form)
+    from tiny_diffusion_amd._lib import lib
+    assert lib.tdx_tune_set(b"bf16_storage", int(os.environ["TDX_BF16_STORAGE"])) == 0
 torch.manual_seed(0)
 if which == "mnist":
     from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
