@@ -1,17 +1,19 @@
-"""GPU: the opt-in bf16 compute mode (BASELINE.json configs[3]/[4] name bf16; the reference itself is
+"""GPU: the opt-in bf16 mode (BASELINE.json configs[3]/[4] name bf16; the reference itself is
 fp32-only, SURVEY.md 0, so there is no reference behaviour to match bit for bit).
 
 Arithmetic: the three 3x3-convolution GEMMs (forward, input gradient, weight gradient) run on
-v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (nearest even) and fp32 accumulation; tensors,
-BatchNorm statistics, BatchNorm, pooling / resizing, the time MLP, the loss and Adam stay fp32.
+v_mfma_f32_32x32x16_bf16 with operands rounded to bf16 (nearest even) and fp32 accumulation.  Since round 3 the
+activation tensors and activation gradients are also STORED in bf16 (every HBM-bound kernel widens on load, computes
+in fp32 and rounds on store: io16.h); BatchNorm statistics / scale / shift, the time MLP, the loss, parameter
+gradients and Adam stay fp32.  The kernel tests below call the fp32-tensor entry points (bf16 operands only).
 
 Tolerances stated here:
   * kernels: against the SAME arithmetic on the CPU (operands rounded to bf16, fp64 accumulation):
     relative error <= 2e-5 (fp32 accumulation order only);
-  * whole network: eps_hat MSE <= 5e-4 against the fp32 vectors of the reference (SURVEY.md 8(c):
-    the reference under bf16 autocast is itself 5e-5 .. 1.5e-4 from fp64), loss within 2 %,
-    parameter gradients at cosine similarity >= 0.95 (worst: a BatchNorm bias twelve layers from the
-    loss at B = 8) and >= 0.99 (median; 0.992 at B = 2, 64x64) with the fp32 oracle's."""
+  * whole network (storage mode): eps_hat MSE <= 5e-4 against the fp32 vectors of the reference (SURVEY.md 8(c):
+    the reference under bf16 autocast is itself 5e-5 .. 1.5e-4 from fp64; measured here 5e-5 .. 3.8e-4), loss
+    within 2 %, parameter gradients at cosine similarity >= 0.93 (worst: a BatchNorm bias at B = 2, 64x64: 0.940)
+    and >= 0.99 (median; 0.9906 in that case) with the fp32 oracle's."""
 import os
 
 import numpy as np
