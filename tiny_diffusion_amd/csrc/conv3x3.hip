@@ -773,6 +773,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   // time_l1_bwd_kernel it gave a wrong dW1 about once in 20-30 steps, cause not found.
   // "time_stage" therefore accepts the default only; tools/gpu_stage6_diag.py uses the _diag key.
   if (!strcmp(key, "time_stage")) { if (value != 14) return TDX_E_BADARG; g_tdx_time_stage = 14; return 0; }
+  if (!strcmp(key, "stats_epi")) { g_conv_dbg = value ? (g_conv_dbg | 8) : (g_conv_dbg & ~8); return 0; }   // 1: one-pass (Chan) statistics epilogue
   if (!strcmp(key, "bf16_storage")) { g_tdx_bf16_storage = value != 0; return 0; }
   if (!strcmp(key, "sample_fuse")) { g_tdx_sample_fuse = value & 7; return 0; }
   if (!strcmp(key, "sample_defer_max")) { g_tdx_sample_defer_max = value; return 0; }

@@ -196,29 +196,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     csum[in] = s;
   }
   if (EPI == EPI_STATS) {
-    float* red = smem;  // [WGM][BN] + [BN] means, re-uses the tile buffers (K loop is over)
-    const int rows_valid = min(BM, a.M - m0);
+    // Per tile and channel: (sum, M2 about the TILE mean), two passes over the accumulators with the tile mean
+    // going through LDS in between (five barriers).  The one-pass alternative below it (round 3, knob
+    // "stats_epi" = 1: every lane centres its 16*TM rows about their own mean, (count, sum, M2) triples merged
+    // pairwise with Chan's formula - lane halves by shuffle, row waves through LDS - two barriers) gives the same
+    // statistics to rounding and was MEASURED no faster (B = 256 step 15.50 vs 15.54 ms): the epilogue's cost is
+    // its stores and the drain of the tile, not its barriers.  Kept as the experiment it was.
+    if (!(a.dbg & 8)) {
+      float* red = smem;  // [WGM][BN] + [BN] means, re-uses the tile buffers (K loop is over)
+      const int rows_valid = min(BM, a.M - m0);
+      __syncthreads();    // every wave is done with the tile buffers
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
+        if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
+      }
+      __syncthreads();
+      float* tsum = red + WGM * BN;  // [BN] tile column sums
+      for (int c = tid; c < BN; c += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+        tsum[c] = v;
+        a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
+      }
+      __syncthreads();
+      const float inv_n = 1.0f / (float)rows_valid;
+      float cm2[TN];
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m0 + row < a.M) {
+              const float dlt = acc[im][in][r] - mean;
+              q = fmaf(dlt, dlt, q);
+            }
+          }
+        cm2[in] = q + __shfl_xor(q, 32, 64);
+      }
+      __syncthreads();  // everyone has read tsum/red
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+        if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
+      __syncthreads();
+      for (int c = tid; c < BN; c += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
+        a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
+      }
+      return;
+    }
+    // rows of this lane that exist (the last row tile may be ragged); the same for every column
+    int nl = 0;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        nl += (m0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) < a.M ? 1 : 0;
+    const float fn = (float)nl;
+    const float fn_o = __shfl_xor(fn, 32, 64);
+    const float fn2 = fn + fn_o;                       // rows of this wave's 32*TM-row slab
+    float* red = smem;  // [3][WGM][BN]: count | sum | M2 of each row wave, re-uses the tile buffers (K loop is over)
     __syncthreads();    // every wave is done with the tile buffers
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      const float s = csum[in] + __shfl_xor(csum[in], 32, 64);
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = s;
-    }
-    __syncthreads();
-    float* tsum = red + WGM * BN;  // [BN] tile column sums
-    for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      tsum[c] = v;
-      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = v;
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)rows_valid;
-    float cm2[TN];
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const float mean = tsum[wn * WTN + in * 32 + l31] * inv_n;
+      const float s = csum[in];
+      const float mean = nl ? s / fn : 0.f;
       float q = 0.f;
 #pragma unroll
       for (int im = 0; im < TM; ++im)
@@ -230,22 +279,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
             q = fmaf(dlt, dlt, q);
           }
         }
-      cm2[in] = q + __shfl_xor(q, 32, 64);
+      // Chan: the other half's (fn_o, s_o, q_o)
+      const float s_o = __shfl_xor(s, 32, 64), q_o = __shfl_xor(q, 32, 64);
+      const float mean_o = fn_o > 0.f ? s_o / fn_o : 0.f;
+      const float d = mean - mean_o;
+      const float w = fn2 > 0.f ? fn * fn_o / fn2 : 0.f;
+      const float s2 = s + s_o, q2 = q + q_o + d * d * w;
+      if (half == 0) {
+        const int c = wn * WTN + in * 32 + l31;
+        red[(0 * WGM + wm) * BN + c] = fn2;
+        red[(1 * WGM + wm) * BN + c] = s2;
+        red[(2 * WGM + wm) * BN + c] = q2;
+      }
     }
-    __syncthreads();  // everyone has read tsum/red
-#pragma unroll
-    for (int in = 0; in < TN; ++in)
-      if (half == 0) red[wm * BN + wn * WTN + in * 32 + l31] = cm2[in];
     __syncthreads();
     for (int c = tid; c < BN; c += 256) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WGM; ++w) v += red[w * BN + c];
-      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = v;
+      const float n0f = red[(0 * WGM + 0) * BN + c], n1f = red[(0 * WGM + 1) * BN + c];
+      const float s0 = red[(1 * WGM + 0) * BN + c], s1 = red[(1 * WGM + 1) * BN + c];
+      const float q0 = red[(2 * WGM + 0) * BN + c], q1 = red[(2 * WGM + 1) * BN + c];
+      const float nt = n0f + n1f;
+      const float d = (n0f > 0.f ? s0 / n0f : 0.f) - (n1f > 0.f ? s1 / n1f : 0.f);
+      const float w = nt > 0.f ? n0f * n1f / nt : 0.f;
+      a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n0 + c] = s0 + s1;
+      a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n0 + c] = q0 + q1 + d * d * w;
     }
   }
 }
-
 
 // ---------------------------------------------------------------------- wgrad
 // GEMM: rows = output channels, cols = input channels of ONE tap, K = pixels, split over pixel chunks
