@@ -231,12 +231,12 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch: int = 64, steps: int = 10, warm: int = 2, sample_steps: int = 20):
+def cpu_baseline(batch: int = 64, steps: int = 24, warm: int = 2, sample_steps: int = 40):
     """the CPU oracle (port of diffusion.py:214-236 and 254-276, checked against
     the reference's own outputs) on ALL host cores of this box, configs[0] (unconditional, B = 64,
-    fp32): 2 warm-up + 10 timed train steps (q_sample + fwd + MSE + bwd + Adam) and 2 + 20 timed
-    reverse steps (eval forward + p_sample), the latter extrapolated x1000/20 to a chain.  A bounded
-    sample, reported beside the GPU number, never the target."""
+    fp32): 2 warm-up + 24 timed train steps (q_sample + fwd + MSE + bwd + Adam) and 2 + 40 timed
+    reverse steps (eval forward + p_sample), the latter extrapolated x1000/40 to a chain - about 15 s of CPU
+    work on 16 threads.  A bounded sample, reported beside the GPU number, never the target."""
     from oracle import ref_cpu as R
     from oracle.weights import make_state_dict
 
@@ -496,6 +496,45 @@ LAION_FWD_FLOP = sum(2 * 9 * ci * co * hw * hw for ci, co, hw in _LAION_CONVS)
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md (dense bf16 matrix; the sparse figure is 2x)
 
+# (cin, cout, hw) of the LAION network's 13 conv/BN units at 32x32 (conditional_diffusion_laion.py:246-295; the first
+# unit's input is stored zero-padded to 64 channels)
+LAION_UNITS = [(64, 64, 32), (64, 64, 32), (64, 128, 16), (128, 128, 16), (128, 256, 8), (256, 256, 8), (256, 256, 4),
+               (512, 256, 8), (256, 256, 8), (384, 128, 16), (128, 128, 16), (192, 64, 32), (64, 64, 32)]
+
+
+def bf16_hbm_roofline(units, B, n_params, ms_per_step):
+    """HBM roofline of a training step in the bf16 mode (bf16 MFMA operands AND bf16 activation tensors): at 16x
+    the fp32 matrix rate the step is bandwidth-bound, so its yardstick is algorithmic bytes / 8 TB/s.  Algorithmic
+    bytes per step = every tensor moved the minimum number of times at its storage width:
+      convolutions   3 roles x (read M*cin + M*cout elements, 2 B each) + bf16 weight packs read 3x + the fp32
+                     weight gradient written once;
+      BatchNorm bwd  read g, read y, write g: 6 B per output element (the reduction rides on the producer);
+      pool / resize / concat   each decoder input written once and each pooled map written once, forward and
+                     backward (2 B/elt; their reads are the convolutions' outputs, counted above);
+      optimizer      28 B per parameter (fp32 p, g, m, v read; p, m, v written).
+    What the kernels actually move on top of that (nine taps re-reading rows through L2, split-K slabs, the
+    BatchNorm reduction passes that are not fused) is the gap `frac` shows."""
+    conv = bn = spatial = wts = 0.0
+    for cin, cout, hw in units:
+        M = B * hw * hw
+        conv += 3 * 2.0 * M * (cin + cout)
+        bn += 6.0 * M * cout
+        wts += 3 * 2.0 * 9 * cin * cout + 4.0 * 9 * cin * cout
+    # decoder inputs (units 7, 9, 11) and pooled maps (inputs of units 2, 4, 6): written once forward, their
+    # gradients once backward
+    for i in (7, 9, 11, 2, 4, 6):
+        cin, _, hw = units[i]
+        spatial += 2 * 2.0 * B * hw * hw * cin
+    adam = 28.0 * n_params
+    total = conv + bn + spatial + wts + adam
+    tbps = total / (ms_per_step * 1e-3) / 1e12
+    return {"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": PEAK_HBM_TBPS * 1e3, "unit": "GB/s",
+            "frac": round(tbps / PEAK_HBM_TBPS, 4), "algorithmic_bytes_per_step": int(total),
+            "breakdown_mb": {"conv_operands": round(conv / 1e6, 1), "batchnorm_backward": round(bn / 1e6, 1),
+                             "pool_resize_concat": round(spatial / 1e6, 1), "weights": round(wts / 1e6, 1),
+                             "optimizer": round(adam / 1e6, 1)},
+            "hbm_time_at_peak_ms": round(total / (PEAK_HBM_TBPS * 1e12) * 1e3, 3)}
+
 
 def laion_extras(steps: int = 30, warmup: int = 6):
     """SURVEY.md 8(f) f3 (BASELINE.json configs[4] shape): training step of the LAION-shaped latent UNet
@@ -546,10 +585,13 @@ def laion_extras(steps: int = 30, warmup: int = 6):
     del model
     out["train_B256"], _, _ = leg(256, 32, torch.float32)
     out["train_B256_hw64"], _, _ = leg(256, 64, torch.float32)
-    bf = {"arithmetic": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation; fp32 tensors, BatchNorm, "
-                        "time MLP, loss, Adam", "peak_tflops": PEAK_BF16_MFMA_TFLOPS}
+    bf = {"arithmetic": "bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation; activations and activation "
+                        "gradients stored in bf16; fp32 parameters, BatchNorm statistics, time MLP, loss, Adam",
+          "peak_tflops": PEAK_BF16_MFMA_TFLOPS}
     for key, B, hw in (("train_B256", 256, 32), ("train_B256_hw64", 256, 64)):
         r, _, _ = leg(B, hw, torch.bfloat16)
+        r["roofline"] = bf16_hbm_roofline([(ci, co, h * hw // 32) for ci, co, h in LAION_UNITS], B, 5_793_124,
+                                          r["ms_per_step"])
         r["frac_of_bf16_mfma_peak"] = round(r["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)
         r["speedup_vs_fp32"] = round(out[key]["ms_per_step"] / r["ms_per_step"], 2)
         bf[key] = r
@@ -585,7 +627,10 @@ def mnist_bf16_leg(fp, steps: int = 30, warmup: int = 6):
             "parity_check": parity,
             "tflops": round(v * TRAIN_FLOP_PER_IMAGE / 1e12, 1),
             "frac_of_bf16_mfma_peak": round(v * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-            "arithmetic": "bf16 MFMA operands, fp32 accumulation and storage (tests/test_gpu_bf16.py)"}
+            "roofline": bf16_hbm_roofline([(ci, co, h) for ci, co, h, _ in UNITS], PER_GPU_BATCH, 11_182_273,
+                                          dt / steps * 1e3),
+            "arithmetic": "bf16 MFMA operands, fp32 accumulation; activations and activation gradients stored in bf16 "
+                          "(tests/test_gpu_bf16.py)"}
 
 
 def latent_extras(steps: int = 200, warmup: int = 20):

@@ -613,9 +613,14 @@ def test_time_dim_constructor_argument(time_dim):
 def test_train_step_graph_capture_three_streams():
     """TrainStep(use_graph=True) on the MNIST network with its default THREE-stream schedule: the captured
     step (helper streams forked inside the capture; the slab reductions move onto the weight-gradient
-    stream for the capture - csrc/unet.hip, tools/micro/capture_fork_probe.hip) replays to the same
-    parameters as the eager step with the same seeds.  Round 2 forced captured steps onto one stream
-    because hipStreamEndCapture crashed; this is the regression test for the real cause."""
+    stream for the capture - csrc/unet.hip, tools/micro/capture_fork_probe.hip) against the eager step with the
+    same seeds.  Round 2 forced captured steps onto one stream because hipStreamEndCapture crashed; this is
+    the regression test for the real cause.  What is compared: the FIRST replayed step's gradient bit for bit
+    (same kernels, same summation orders) and its parameters to fp32 rounding of the step scalars (graph mode
+    takes lr / bias corrections from a device tensor filled by Python doubles, eager mode from C floats); later
+    steps only through the loss - at B = 16 a 1e-8 relative perturbation of the parameters flips near-tied ReLUs
+    and moves single gradient elements by tens of percent within two steps (tools/gpu_graph_vs_eager.py: both
+    paths are individually bit-reproducible, on one stream just the same)."""
     from tiny_diffusion_amd.diffusion import ForwardProcess
     from tiny_diffusion_amd.train import TrainStep
 
@@ -629,14 +634,17 @@ def test_train_step_graph_capture_three_streams():
         ts = TrainStep(m, fp, lr=1e-4, use_graph=use_graph)
         assert m._stream_mode == -1          # the schedule is not overridden for the capture any more
         torch.manual_seed(5); torch.cuda.manual_seed(5)
-        losses = [float(ts.step(x)) for x in xs]
+        rec = []
+        for x in xs:
+            loss = float(ts.step(x))
+            rec.append((loss, ts.flat_grad.clone(), ts.flat_param.clone()))
         assert (ts._graph is not None) == use_graph
-        out.append((losses, ts.flat_param.clone()))
-    (l0, p0), (l1, p1) = out
-    assert np.allclose(l0, l1, rtol=1e-5), (l0, l1)
-    # (lr / bias-correction scalars are rounded to fp32 on the host in graph mode, in C in eager mode: elements
-    # whose |g| ~ eps move by a different fraction of a step; lr = 1e-4)
-    assert (p0 - p1).abs().max().item() <= 2e-5
+        out.append(rec)
+    eager, graph = out
+    assert torch.equal(eager[0][1], graph[0][1]) and torch.equal(eager[0][2], graph[0][2])   # step 1 is eager in both
+    assert torch.equal(eager[1][1], graph[1][1]), "first replayed step: gradients differ from the eager step"
+    assert (eager[1][2] - graph[1][2]).abs().max().item() <= 1e-9
+    assert np.allclose([r[0] for r in eager], [r[0] for r in graph], rtol=1e-4), ([r[0] for r in eager], [r[0] for r in graph])
 
 
 @pytest.mark.parametrize("cond,training,B", [(False, True, 33), (True, False, 7), (False, True, 256)])

@@ -217,6 +217,8 @@ class NoiseModelBase(nn.Module):
     """Shared implementation; ``NoiseModel`` in diffusion.py / conditional_diffusion.py /
     conditional_diffusion_laion.py fixes ``num_classes`` and the architecture."""
 
+    MAX_PLANS = 6   # per-(device, batch, resolution) plans kept per module (LRU; see _plan)
+
     def __init__(self, time_dim: Optional[int] = None, num_classes: int = 0, arch: _Arch = ARCH_MNIST):
         super().__init__()
         time_dim = arch.time_dim if time_dim is None else int(time_dim)
@@ -377,11 +379,16 @@ class NoiseModelBase(nn.Module):
         reference's (LAION network only)."""
         dev = device.index if device.index is not None else torch.cuda.current_device()
         key = (dev, batch) if not hw else (dev, batch, hw)
-        p = self._plans.get(key)
+        p = self._plans.pop(key, None)
         if p is None:
             p = _Plan(batch, self.num_classes, device, self._arch.kind, hw,
                       0 if self.time_dim == self._arch.time_dim else self.time_dim)
-            self._plans[key] = p
+            # A plan owns its workspace (~12 MB per image for the MNIST UNet: 3 GB at B = 256).  A loop over many
+            # batch sizes (ragged last batches, evaluation sweeps) must not accumulate them: keep the MAX_PLANS most
+            # recently used; an evicted plan stays alive only while an autograd graph still refers to it.
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = p   # (re-)inserted last: dicts keep insertion order, so the first key is the LRU one
         return p
 
     def _input_hw(self, x) -> int:
