@@ -19,6 +19,22 @@ run rocprofv3 --pmc MfmaUtil --output-format csv -d gpurun_out/${tag}_pmc_mfma -
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -- python3 bench.py --train-only --steps 30 --warmup 5 > gpurun_out/${tag}_train.json 2> gpurun_out/${tag}_train.err && echo train ok &&
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bench -- python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_bench.err && echo bench ok
 rc=$?
+# conversions into the files kept under profiles/ (small; done here so that they travel back with gpurun_out/)
+sha=gpurun_out/${tag}_src_sha256.txt
+out=gpurun_out/${tag}_profiles
+mkdir -p $out
+python3 tools/pmc_traffic.py gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w $out/${tag}_pmc_hbm_traffic $sha > /dev/null
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_mfma MfmaUtil $out/${tag}_pmc_MfmaUtil.txt > /dev/null
+trace=$(ls gpurun_out/${tag}_train/*/*kernel_trace.csv | head -n 1)
+python3 tools/insitu.py $trace $out/${tag}_insitu.json $sha > /dev/null
+python3 tools/step_timeline.py $trace 10 > $out/${tag}_step_timeline.txt
+cp $(ls gpurun_out/${tag}_roof/*/*kernel_stats.csv | head -n 1) $out/${tag}_roofline_leg_kernel_stats.csv
+cp $(ls gpurun_out/${tag}_train/*/*kernel_stats.csv | head -n 1) $out/${tag}_train_only_kernel_stats.csv
+cp $(ls gpurun_out/${tag}_bench/*/*kernel_stats.csv | head -n 1) $out/${tag}_bench_default_kernel_stats.csv
+cp gpurun_out/${tag}_roof.json $out/${tag}_roofline_leg.json
+cp gpurun_out/${tag}_bench_under_rocprof.json $out/${tag}_bench_default_under_rocprof.json
+cp $sha $out/
+rm -rf gpurun_out/${tag}_roof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w gpurun_out/${tag}_pmc_mfma gpurun_out/${tag}_train gpurun_out/${tag}_bench
 # the per-dispatch traces of the long legs are large (two 1000-step chains): keep the stats only
 find gpurun_out/${tag}_bench gpurun_out/${tag}_roof -name "*kernel_trace.csv" -delete 2>/dev/null
 du -sh gpurun_out/${tag}_* 2>/dev/null
