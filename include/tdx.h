@@ -232,6 +232,15 @@ int tdx_conv3x3_wgrad_reduce(const float* dw_slabs, float* dw_oihw, int splits, 
  * path's slab layout (same reduce) in tdx_conv3x3_wgrad_splits_bf16(...) slabs - its own split plan: the
  * bf16 kernel is bound by L2 bandwidth, not MFMA rate, and wants bigger tiles.  Tolerance: tests/test_gpu_bf16.py. */
 int tdx_conv3x3_wgrad_splits_bf16(int B, int H, int W, int cin, int cout);
+/* The bf16 STORAGE forms (round 3): io16 != 0 -> `in`, `out` / `dy` hold bf16 elements (the activation tensors of
+ * a plan in bf16 mode); io16 == 0 -> exactly tdx_conv3x3_fwd_bf16 / tdx_conv3x3_wgrad_bf16.  bias, scale / shift,
+ * statistics partials and the weight-gradient slabs are fp32 either way. */
+int tdx_conv3x3_fwd_bf16_io(const void* in, const void* wpk_bf16, const float* bias, void* out, int B, int H, int W,
+                            int cin, int cout, int flags, const float* in_scale, const float* in_shift,
+                            const float* out_scale, const float* out_shift, float* stats_partial, int io16,
+                            tdx_stream_t stream);
+int tdx_conv3x3_wgrad_bf16_io(const void* in, const void* dy, float* dw_slabs, int B, int H, int W, int cin, int cout,
+                              int flags, const float* in_scale, const float* in_shift, int io16, tdx_stream_t stream);
 int tdx_pack_conv3x3_bf16(const float* w_oihw, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin,
                           tdx_stream_t stream);
 int tdx_conv3x3_bf16_stat_tile_rows(void);

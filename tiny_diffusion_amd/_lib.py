@@ -89,6 +89,8 @@ _SIGS = {
     "tdx_conv3x3_wgrad_splits": (C.c_int, [C.c_int] * 5),
     "tdx_diag_conv_occupancy": (C.c_int, [C.c_int]),
     "tdx_conv3x3_wgrad_splits_bf16": (C.c_int, [C.c_int] * 5),
+    "tdx_conv3x3_fwd_bf16_io": (C.c_int, [_ptr] * 4 + [C.c_int] * 6 + [_ptr] * 5 + [C.c_int, _ptr]),
+    "tdx_conv3x3_wgrad_bf16_io": (C.c_int, [_ptr] * 3 + [C.c_int] * 6 + [_ptr] * 2 + [C.c_int, _ptr]),
     "tdx_conv3x3_shape_ok": (C.c_int, [C.c_int] * 5),
     "tdx_conv3x3_tile_shape": (C.c_int, [C.c_int] * 6),
     "tdx_conv3x3_wgrad": (C.c_int, [_ptr, _ptr, _ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -709,6 +709,7 @@ static int g_conv_impl = 0;           // main-loop variant of the non-split laun
                                       // (default: fastest end to end in in-process A/B), 1 two stages,
                                       // 2 two stages + sched_group_barrier interleave
 static int g_conv_dbg = 0;
+int tdx_conv_dbg_get() { return g_conv_dbg; }
 static int g_conv_stamp = 0;           // diagnostics: LDS-DMA forward kernels stamp their main loop into the diag buffer
 extern unsigned* g_tdx_diag_buffer;    // time_embed.hip (tdx_diag_set_buffer)
 extern size_t g_tdx_diag_bytes;
@@ -1640,7 +1641,7 @@ static WgradCfg pick_wgrad_legacy(int64_t M, int cin, int cout, bool bf16) {
   int64_t tiles = (int64_t)(cout / c.bm) * (cin / c.bn) * 9;
   const int target = (c.bm == 128 && c.bn == 128 && g_wgrad_target_big > 0) ? g_wgrad_target_big : g_wgrad_target;
   int64_t s = (target + tiles - 1) / tiles;
-  if (!bf16 && g_wgrad_plan == 1 && c.bm == c.bn) {
+  if (!bf16 && ((g_wgrad_plan == 1 && c.bm == c.bn) || g_wgrad_plan == 3)) {   // 3: rectangular tiles too (A/B)
     // Both targets are two rounds of the chip's workgroup slots (64x64: 4 per CU, 128x128: 2; lds_slots_per_cu),
     // but rounding the split count UP put most layers a few workgroups ABOVE two rounds (2052 on 1024 slots,
     // 1044 on 512), i.e. into a third round for 4 of them: isolated, 554 -> 463 us (256 -> 256 at 14x14),
@@ -1748,7 +1749,7 @@ extern "C" int tdx_conv3x3_wgrad(const float* in, const float* dy, float* dw_sla
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   a.tilesCi = cin / c.bn; a.tilesCo = cout / c.bm; a.chunk = c.chunk;
   a.groups = a.tilesCi * a.tilesCo * c.splits;
-  a.adv_q = 32 / W; a.adv_s = 32 % W;
+  a.adv_q = 32 / W; a.adv_s = 32 % W; a.dbg = 0;
   if (H < 4 && 32 / W + 1 >= 2 * H) return TDX_E_SHAPE;  // two conditional subtracts must suffice
   hipStream_t st = to_stream(stream);
   if (c.bm == 128 && c.bn == 128) return launch_wgrad<128, 128>(a, c.splits, in_bn, st);

@@ -14,6 +14,7 @@
 // producing layer is applied while staging (VALU is free here, so nothing is materialised), and the
 // nine taps of a tile re-read their rows from L1/L2.
 #include "conv_shared.h"
+#include <type_traits>
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -181,24 +182,40 @@ conv3x3_bf16_kernel(ConvArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
   };
-  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
-    load_tile(kt + 2, Sld);                 // (clamped at the end: a redundant re-load, never stored)
+  // NS register stages (round 3: three in bf16-storage mode, where a stage is half the registers): iteration kt
+  // issues the loads of tile kt+NS into the stage whose tile (kt) went to LDS in the previous iteration, multiplies
+  // tile kt from LDS[kt&1] and stores tile kt+1 (loaded NS-1 iterations ago) into the other LDS buffer - NS-1 tiles of
+  // loads are in flight at any time instead of one (16 MFMAs = 0.2 us per K-tile against a 1-2 us round trip).
+  constexpr int NS = IO16 ? 3 : 2;
+  Stage S2;
+  auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {
+    const int cur = kt & 1;
+    if (!(a.dbg & 64)) load_tile(kt + NS, Sld);   // (clamped at the end: a redundant re-load, never stored)
     __builtin_amdgcn_sched_barrier(0);      // keep the loads at the top: hipcc otherwise sinks them
-    compute(cur);
+    if (!(a.dbg & 16)) compute(cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) store_tile(Sst, cur ^ 1);
+    if (kt + 1 < nk && !(a.dbg & 32)) store_tile(Sst, cur ^ 1);
     __syncthreads();
   };
   load_tile(0, S0);
   load_tile(1, S1);
+  if (NS == 3) load_tile(2, S2);
   store_tile(S0, 0);
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    iteration(kt, 0, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
-    iteration(kt + 1, 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
+  if (NS == 2) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      iteration(kt, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
+      iteration(kt + 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
+    }
+    if (kt < nk) iteration(kt, S1, S0);
+  } else {
+    for (int kt = 0; kt < nk; kt += 3) {
+      iteration(kt, S1, S0);                      // tile kt+1 in S1; tile kt+3 -> S0
+      if (kt + 1 < nk) iteration(kt + 1, S2, S1); // tile kt+2 in S2; tile kt+4 -> S1
+      if (kt + 2 < nk) iteration(kt + 2, S0, S2); // tile kt+3 in S0; tile kt+5 -> S2
+    }
   }
-  if (kt < nk) iteration(kt, 0, S1, S0);
   conv_epilogue<BM, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw), tile_m, m0, n0, wm, wn, l31, half,
                                     tid);
 }
@@ -287,8 +304,9 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
 
   // two register stages, as in conv3x3_bf16_kernel: the loads of pixel-tile kt+2 are in flight while
   // tile kt is multiplied and tile kt+1 is converted, transposed and stored
+  typedef typename std::conditional<IO16, u32x2, f32x4>::type SReg;   // 4 channels of one pixel: 8 B of bf16 or 16 B of fp32
   struct Stage {
-    f32x4 ra[APASS][4], rb[BPASS][4];
+    SReg ra[APASS][4], rb[BPASS][4];
     unsigned okB;  // bit (q*4 + e): pixel e of group q has its tap inside the image
   };
   Stage S0, S1;
@@ -301,13 +319,12 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     const int pbase = p_lo + kt * KT;
     const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * ES;
     const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * ES + tap_shift;
-    // IO16: four bf16 per load land in the first two dwords of the stage register (the other two stay unused)
-    auto ldx = [&](decltype(rsrc_dy) rs, unsigned voff, unsigned soff) -> f32x4 {
-      if (IO16) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-        return __builtin_bit_cast(f32x4, u32x4{v[0], v[1], 0u, 0u});
+    auto ldx = [&](decltype(rsrc_dy) rs, unsigned voff, unsigned soff) -> SReg {
+      if constexpr (IO16) {
+        return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+      } else {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
       }
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
 #pragma unroll
     for (int q = 0; q < APASS; ++q)
@@ -342,10 +359,13 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
     __bf16* Ab = As + buf * BM * KTP;
     __bf16* Bb = Bs + buf * BN * KTP;
     // the 4 channels of pixel e of a stage register as floats (IO16: widened from the bf16 pack in its low half)
-    auto wide = [&](const f32x4& r) -> f32x4 {
-      if (!IO16) return r;
-      const bf16x8 h = __builtin_bit_cast(bf16x8, r);
-      return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    auto wide = [&](const SReg& r) -> f32x4 {
+      if constexpr (IO16) {
+        const bf16x4 h = __builtin_bit_cast(bf16x4, r);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        return r;
+      }
     };
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
@@ -394,26 +414,47 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
   };
-  auto iteration = [&](int kt, int cur, const Stage& Sst, Stage& Sld) {
-    load_tile(kt + 2, Sld);
+  // register stages (see conv3x3_bf16_kernel; tiles are requested strictly in order): four where they fit 256 registers
+  constexpr int NS = IO16 ? (BM == 128 && BN == 128 ? 3 : 4) : 2;
+  Stage S2, S3;
+  auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {
+    const int cur = kt & 1;
+    if (!(a.dbg & 64)) load_tile(kt + NS, Sld);
     __builtin_amdgcn_sched_barrier(0);
-    compute(cur);
+    if (!(a.dbg & 16)) compute(cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) store_tile(Sst, cur ^ 1);
+    if (kt + 1 < nk && !(a.dbg & 32)) store_tile(Sst, cur ^ 1);
     __syncthreads();
   };
   if (nk > 0) {
     load_tile(0, S0);
     load_tile(1, S1);
+    if (NS >= 3) load_tile(2, S2);
+    if (NS == 4) load_tile(3, S3);
     store_tile(S0, 0);
   }
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    iteration(kt, 0, S1, S0);
-    iteration(kt + 1, 1, S0, S1);
+  if (NS == 2) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      iteration(kt, S1, S0);
+      iteration(kt + 1, S0, S1);
+    }
+    if (kt < nk) iteration(kt, S1, S0);
+  } else if (NS == 3) {
+    for (int kt = 0; kt < nk; kt += 3) {
+      iteration(kt, S1, S0);
+      if (kt + 1 < nk) iteration(kt + 1, S2, S1);
+      if (kt + 2 < nk) iteration(kt + 2, S0, S2);
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 4) {
+      iteration(kt, S1, S0);
+      if (kt + 1 < nk) iteration(kt + 1, S2, S1);
+      if (kt + 2 < nk) iteration(kt + 2, S3, S2);
+      if (kt + 3 < nk) iteration(kt + 3, S0, S3);
+    }
   }
-  if (kt < nk) iteration(kt, 0, S1, S0);
 
   float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll
@@ -521,7 +562,7 @@ extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const
 }
 
 // io16: `in` and `out` hold bf16 (bf16 storage mode; the C-ABI entry above is the fp32-tensor form)
-int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, const float* bias, void* out_, int B, int H, int W,
+extern "C" int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, const float* bias, void* out_, int B, int H, int W,
                             int cin, int cout, int flags, const float* in_scale, const float* in_shift,
                             const float* out_scale, const float* out_shift, float* stats_partial, int io16,
                             tdx_stream_t stream) {
@@ -539,7 +580,7 @@ int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, const float* 
   a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
   a.stats = stats_partial;
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)((int64_t)B * H * W);
-  a.splits = 1; a.kt_per_split = 0; a.dbg = 0; a.stamps = nullptr;
+  a.splits = 1; a.kt_per_split = 0; a.dbg = tdx_conv_dbg_get(); a.stamps = nullptr;
   a.out_bf16 = io16 ? 1 : 0;
   hipStream_t st = to_stream(stream);
   // memory-bound: the widest column tile re-reads the input least often
@@ -580,7 +621,7 @@ extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* d
   return tdx_conv3x3_wgrad_bf16_io(in, dy, dw_slabs, B, H, W, cin, cout, flags, in_scale, in_shift, 0, stream);
 }
 
-int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float* dw_slabs, int B, int H, int W, int cin, int cout,
+extern "C" int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float* dw_slabs, int B, int H, int W, int cin, int cout,
                               int flags, const float* in_scale, const float* in_shift, int io16, tdx_stream_t stream) {
   const float* in = static_cast<const float*>(in_);
   const float* dy = static_cast<const float*>(dy_);
@@ -597,7 +638,7 @@ int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float* dw_slabs,
   a.B = B; a.H = H; a.W = W; a.Cin = cin; a.Cout = cout; a.M = (int)M64;
   a.tilesCi = cin / bn; a.tilesCo = cout / bm; a.chunk = chunk;
   a.groups = a.tilesCi * a.tilesCo * splits;
-  a.adv_q = 0; a.adv_s = 0;
+  a.adv_q = 0; a.adv_s = 0; a.dbg = tdx_conv_dbg_get();
   hipStream_t st = to_stream(stream);
 #define TDX_WG(BM_, BN_) (io16 ? launch_wgrad_bf16<BM_, BN_, true>(a, in_bn, st) : launch_wgrad_bf16<BM_, BN_, false>(a, in_bn, st))
   if (bm == 128 && bn == 128) return TDX_WG(128, 128);

@@ -166,10 +166,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     }
     return;
   }
+  // bf16 OUTPUT (bf16 storage mode): in the accumulator layout a wave-instruction covers two rows x 32 columns, i.e.
+  // two 64-byte half lines per store when the elements are 2 bytes wide - the input gradient of dec1.0 (134 MB of
+  // output from nine K-tiles of work) took 490 us that way.  The tile is rounded into LDS instead (the K loop is
+  // over; pitch BN + 8 elements) and written out as whole rows, 16 bytes per lane.
+  const bool stage16 = a.out_bf16 != 0;   // workgroup-uniform
+  constexpr int CPITCH = BN + 8;
+  __bf16* ctile = reinterpret_cast<__bf16*>(smem);
+  if (stage16) __syncthreads();           // every wave is done with the tile buffers
   float csum[TN];
 #pragma unroll
   for (int in = 0; in < TN; ++in) {
-    const int col = n0 + wn * WTN + in * 32 + l31;
+    const int lcol = wn * WTN + in * 32 + l31;
+    const int col = n0 + lcol;
     const float bv = a.bias ? a.bias[col] : 0.f;
     float osc = 1.f, osh = 0.f;
     if (EPI == EPI_BNRELU) {
@@ -187,13 +196,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         if (EPI == EPI_BNRELU) v = fmaxf(fmaf(v, osc, osh), 0.f);
         acc[im][in][r] = v;
         if (p < a.M) {
-          if (a.out_bf16) reinterpret_cast<__bf16*>(a.out)[(size_t)p * a.Cout + col] = (__bf16)v;
+          if (stage16) ctile[row * CPITCH + lcol] = (__bf16)v;
           else a.out[(size_t)p * a.Cout + col] = v;
           s += v;
         }
       }
     }
     csum[in] = s;
+  }
+  if (stage16) {
+    __syncthreads();
+    constexpr int CH = BN / 8;   // 16-byte chunks per tile row
+    __bf16* out16 = reinterpret_cast<__bf16*>(a.out);
+    for (int c = tid; c < BM * CH; c += 256) {
+      const int row = c / CH, cc = c - row * CH;
+      if (m0 + row < a.M)
+        *reinterpret_cast<f32x4*>(out16 + (size_t)(m0 + row) * a.Cout + n0 + cc * 8) =
+            *reinterpret_cast<const f32x4*>(ctile + row * CPITCH + cc * 8);
+    }
+    // (the statistics code below opens with a barrier of its own before it re-uses this LDS)
   }
   if (EPI == EPI_STATS) {
     // Per tile and channel: (sum, M2 about the TILE mean), two passes over the accumulators with the tile mean
@@ -317,6 +338,8 @@ struct WgradArgs {
   const float* in_shift;
   int B, H, W, Cin, Cout, M, tilesCi, tilesCo, groups, chunk;
   int adv_q, adv_s;  // 32 pixels = adv_q rows + adv_s columns of a W-wide image
+  int dbg;           // ablation bits of the bf16 kernels (tdx_tune_set("conv_dbg")): 16 no MFMA, 32 no LDS staging, 64 no loads
 };
+int tdx_conv_dbg_get();
 
 void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk, bool bf16 = false);

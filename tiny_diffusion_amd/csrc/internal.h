@@ -81,13 +81,6 @@ extern int g_tdx_time_l1_impl;   // diagnostic: 1 = first version of time_l1_bwd
 extern int g_tdx_input_copy;     // diagnostic: 1 = forward keeps its inputs with a copy KERNEL instead of hipMemcpyAsync
 int tdx_time_embed_only(const int64_t* t, const int64_t* y, const float* const* P, float* pre, float* emb,
                         float* tf_out, int B, hipStream_t st);
-// bf16 compute mode with bf16 STORAGE of the activation tensors (conv3x3_bf16.hip): io16 = `in` / `out` / `dy` hold bf16
-int tdx_conv3x3_fwd_bf16_io(const void* in, const void* wpk_bf16, const float* bias, void* out, int B, int H, int W,
-                            int cin, int cout, int flags, const float* in_scale, const float* in_shift,
-                            const float* out_scale, const float* out_shift, float* stats_partial, int io16,
-                            tdx_stream_t stream);
-int tdx_conv3x3_wgrad_bf16_io(const void* in, const void* dy, float* dw_slabs, int B, int H, int W, int cin, int cout,
-                              int flags, const float* in_scale, const float* in_shift, int io16, tdx_stream_t stream);
 // sampling tables (time_embed.hip) and the pieces of a table-mode reverse step
 int tdx_time_tables_build(int kind, const float* const* P, int T, int td, float* tab1, float* tab2, float* tab3,
                           float* scratch, hipStream_t st);
