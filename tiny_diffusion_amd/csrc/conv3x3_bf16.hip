@@ -19,6 +19,8 @@
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define KT 64    // K-tile (bf16 elements): 64 channels of one tap / 64 pixels (wgrad)
@@ -182,15 +184,11 @@ conv3x3_bf16_kernel(ConvArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
   };
-  // NS register stages (round 3: three in bf16-storage mode, where a stage is half the registers): iteration kt
-  // issues the loads of tile kt+NS into the stage whose tile (kt) went to LDS in the previous iteration, multiplies
-  // tile kt from LDS[kt&1] and stores tile kt+1 (loaded NS-1 iterations ago) into the other LDS buffer - NS-1 tiles of
-  // loads are in flight at any time instead of one (16 MFMAs = 0.2 us per K-tile against a 1-2 us round trip).
-  constexpr int NS = IO16 ? 3 : 2;
-  Stage S2;
+  // (a third register stage - the loads of tile kt+3 in flight too - measured no faster in bf16-storage mode: the loop
+  // is not waiting for its loads, see conv3x3_wgrad_bf16s_kernel)
   auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {
     const int cur = kt & 1;
-    if (!(a.dbg & 64)) load_tile(kt + NS, Sld);   // (clamped at the end: a redundant re-load, never stored)
+    if (!(a.dbg & 64)) load_tile(kt + 2, Sld);   // (clamped at the end: a redundant re-load, never stored)
     __builtin_amdgcn_sched_barrier(0);      // keep the loads at the top: hipcc otherwise sinks them
     if (!(a.dbg & 16)) compute(cur);
     __builtin_amdgcn_sched_barrier(0);
@@ -199,23 +197,14 @@ conv3x3_bf16_kernel(ConvArgs a) {
   };
   load_tile(0, S0);
   load_tile(1, S1);
-  if (NS == 3) load_tile(2, S2);
   store_tile(S0, 0);
   __syncthreads();
-  if (NS == 2) {
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      iteration(kt, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
-      iteration(kt + 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
-    }
-    if (kt < nk) iteration(kt, S1, S0);
-  } else {
-    for (int kt = 0; kt < nk; kt += 3) {
-      iteration(kt, S1, S0);                      // tile kt+1 in S1; tile kt+3 -> S0
-      if (kt + 1 < nk) iteration(kt + 1, S2, S1); // tile kt+2 in S2; tile kt+4 -> S1
-      if (kt + 2 < nk) iteration(kt + 2, S0, S2); // tile kt+3 in S0; tile kt+5 -> S2
-    }
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
+    iteration(kt + 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
   }
+  if (kt < nk) iteration(kt, S1, S0);
   conv_epilogue<BM, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw), tile_m, m0, n0, wm, wn, l31, half,
                                     tid);
 }
@@ -414,12 +403,9 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
   };
-  // register stages (see conv3x3_bf16_kernel; tiles are requested strictly in order): four where they fit 256 registers
-  constexpr int NS = IO16 ? (BM == 128 && BN == 128 ? 3 : 4) : 2;
-  Stage S2, S3;
   auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {
     const int cur = kt & 1;
-    if (!(a.dbg & 64)) load_tile(kt + NS, Sld);
+    if (!(a.dbg & 64)) load_tile(kt + 2, Sld);
     __builtin_amdgcn_sched_barrier(0);
     if (!(a.dbg & 16)) compute(cur);
     __builtin_amdgcn_sched_barrier(0);
@@ -429,31 +415,265 @@ conv3x3_wgrad_bf16_kernel(WgradArgs a) {
   if (nk > 0) {
     load_tile(0, S0);
     load_tile(1, S1);
-    if (NS >= 3) load_tile(2, S2);
-    if (NS == 4) load_tile(3, S3);
     store_tile(S0, 0);
   }
   __syncthreads();
-  if (NS == 2) {
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      iteration(kt, S1, S0);
-      iteration(kt + 1, S0, S1);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    iteration(kt, S1, S0);
+    iteration(kt + 1, S0, S1);
+  }
+  if (kt < nk) iteration(kt, S1, S0);
+
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * WTM + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wn * WTN + in * 32 + l31;
+        slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[im][in][r];
+      }
+}
+
+// ------------------------------------------------------------------- wgrad, bf16 storage (round 3)
+// The kernel above, re-staged for bf16 tensors.  Measured with its ablation bits (tools/gpu_bf16_layers.py, MNIST
+// B = 256): weight-gradient launches 1947 us in all, 1238 without the LDS staging, 1610 without the global loads,
+// 324 with neither and no MFMA - the transposing stage, not the matrix core, set the time: its 8-byte LDS writes went
+// to rows 4 apart at a 144-byte pitch, i.e. to 4 of the 32 banks per 16-lane group (8-way conflicts), and a thread
+// fetched 8 bytes per load.  Here a thread loads PG pixels x 8 channels with 16-byte loads (PG = 4 for a 128-channel
+// operand, 2 for a 64-channel one), transposes 16-bit elements with v_perm_b32 (no conversion; the BN+ReLU variant
+// packs with v_cvt_pk_bf16_f32 instead) and writes PG pixels of one channel per store into LDS[channel][pixel] with
+// a 160-byte pitch and the 16-byte chunk index XOR-ed with bits (3, 5, 6) of the row: 2-way on the stores (8 LDS
+// cycles against the 6 a ds_write_b64 costs anyway), conflict-free on the ds_read_b128 operand reads.
+#define KTW 80   // LDS pitch in elements of the swizzled image (72 measured 5 % slower: conflicts)
+__device__ __forceinline__ int wg_swz(int row) { return ((row >> 3) & 1) | (((row >> 5) & 1) << 1) | (((row >> 6) & 1) << 2); }
+
+template <int BM, int BN, bool IN_BN>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wgrad_bf16s_kernel(WgradArgs a) {
+  constexpr int WGN = 2;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int NCA = BM / 8, NCB = BN / 8;      // 16-byte chunks per pixel
+  constexpr int PGA = NCA / 4, PGB = NCB / 4;    // pixels per thread: 256 threads cover KT = 64 pixels x NC chunks
+  static_assert((PGA == 2 || PGA == 4) && (PGB == 2 || PGB == 4), "64- or 128-channel operands");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [2][BM][KTW]  dy^T
+  __bf16* Bs = As + 2 * BM * KTW;                    // [2][BN][KTW]  in^T (shifted by the tap)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int L = blockIdx.x;
+  const int g = (L / 72) * 8 + (L % 8);
+  const int tap = (L % 72) / 8;
+  if (g >= a.groups) return;
+  const int tiles = a.tilesCo * a.tilesCi;
+  const int split = g / tiles, tl = g % tiles;
+  const int tile_co = tl / a.tilesCi, tile_ci = tl % a.tilesCi;
+  const int co0 = tile_co * BM, ci0 = tile_ci * BN;
+  const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+  const int HW = a.H * a.W;
+  const int p_lo = split * a.chunk;
+  const int p_hi = min(p_lo + a.chunk, a.M);
+  const int nk = (p_hi - p_lo + KT - 1) / KT;
+
+  const int a_c8 = tid % NCA, a_pg = tid / NCA;
+  const int b_c8 = tid % NCB, b_pg = tid / NCB;
+  constexpr unsigned OOB = 0x80000000u;
+  const int neg = (a.W + 1) * a.Cin;
+  // the dy descriptor ENDS at this workgroup's last pixel: the ragged end of the range reads zeros
+  const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0,
+                                                         (int)((int64_t)p_hi * a.Cout * 2), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(a.in)) - (int64_t)neg * 2, 0,
+      (int)(((int64_t)a.M * a.Cin + 2 * neg) * 2), 0x00020000);
+  const unsigned tap_shift = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin) * 2u;
+  const unsigned a_off = (unsigned)((a_pg * PGA) * a.Cout + co0 + a_c8 * 8) * 2u;
+  const unsigned b_off = (unsigned)((b_pg * PGB) * a.Cin + ci0 + b_c8 * 8) * 2u;
+  // (oh, ow) of the first pixel this thread stages for B; advanced by KT pixels per K-tile (tiles are requested in order)
+  int b_oh, b_ow;
+  {
+    const int r = (p_lo + b_pg * PGB) % HW;
+    b_oh = r / a.W;
+    b_ow = r % a.W;
+  }
+  // one K-tile further = KT mod HW pixels further in the image: adv_q rows (< H) and adv_s columns, one carry each
+  const int adv_r = KT % HW;
+  const int adv_q = adv_r / a.W, adv_s = adv_r % a.W;
+  float sc8[8], sh8[8];
+  if (IN_BN) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      sc8[c] = a.in_scale[ci0 + b_c8 * 8 + c];
+      sh8[c] = a.in_shift[ci0 + b_c8 * 8 + c];
     }
-    if (kt < nk) iteration(kt, S1, S0);
-  } else if (NS == 3) {
-    for (int kt = 0; kt < nk; kt += 3) {
-      iteration(kt, S1, S0);
-      if (kt + 1 < nk) iteration(kt + 1, S2, S1);
-      if (kt + 2 < nk) iteration(kt + 2, S0, S2);
+  }
+  // LDS element offsets of this thread's transposed stores (row 8*c8 + c adds c * KTW) and of its operand reads
+  const int a_st = (8 * a_c8) * KTW + (PGA == 4 ? (((a_pg >> 1) ^ wg_swz(8 * a_c8)) * 8 + (a_pg & 1) * 4)
+                                                : (((a_pg >> 2) ^ wg_swz(8 * a_c8)) * 8 + (a_pg & 3) * 2));
+  const int b_st = (8 * b_c8) * KTW + (PGB == 4 ? (((b_pg >> 1) ^ wg_swz(8 * b_c8)) * 8 + (b_pg & 1) * 4)
+                                                : (((b_pg >> 2) ^ wg_swz(8 * b_c8)) * 8 + (b_pg & 3) * 2));
+  int a_rd[TM], a_sw[TM], b_rd[TN], b_sw[TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im) {
+    const int row = wm * WTM + im * 32 + l31;
+    a_rd[im] = row * KTW;
+    a_sw[im] = wg_swz(row) ^ half;
+  }
+#pragma unroll
+  for (int in = 0; in < TN; ++in) {
+    const int row = wn * WTN + in * 32 + l31;
+    b_rd[in] = row * KTW;
+    b_sw[in] = wg_swz(row) ^ half;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  struct Stage {
+    u32x4 ra[PGA], rb[PGB];
+    unsigned okB;  // bit e: pixel e of this thread's group has its tap inside the image
+  };
+  Stage S0, S1;
+
+  int tiles_issued = 0;
+  auto load_tile = [&](int kt_req, Stage& S) {
+    const int kt = min(kt_req, nk - 1);           // clamped tail requests re-load the last tile (never stored)
+    const bool advance = kt_req > 0 && kt_req < nk && kt_req == tiles_issued;
+    if (kt_req == tiles_issued) ++tiles_issued;
+    const int pbase = p_lo + kt * KT;
+    const unsigned soff_a = (unsigned)pbase * (unsigned)a.Cout * 2u;
+    const unsigned soff_b = (unsigned)pbase * (unsigned)a.Cin * 2u + tap_shift;
+#pragma unroll
+    for (int e = 0; e < PGA; ++e)
+      S.ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, a_off + (unsigned)(e * a.Cout) * 2u, soff_a, 0);
+    {
+      int ow = b_ow + adv_s, oh = b_oh + adv_q;
+      const bool cw = ow >= a.W;
+      ow = cw ? ow - a.W : ow;
+      oh = cw ? oh + 1 : oh;
+      oh = oh >= a.H ? oh - a.H : oh;
+      b_ow = advance ? ow : b_ow;
+      b_oh = advance ? oh : b_oh;
     }
-  } else {
-    for (int kt = 0; kt < nk; kt += 4) {
-      iteration(kt, S1, S0);
-      if (kt + 1 < nk) iteration(kt + 1, S2, S1);
-      if (kt + 2 < nk) iteration(kt + 2, S3, S2);
-      if (kt + 3 < nk) iteration(kt + 3, S0, S3);
+    int oh = b_oh, ow = b_ow;
+    const int pix0 = pbase + b_pg * PGB;
+    unsigned okB = 0;
+#pragma unroll
+    for (int e = 0; e < PGB; ++e) {
+      const int ih = oh + dh, iw = ow + dw;
+      // (pixels past the tensor are refused too: their dy rows are zero, but 0 * garbage may be NaN)
+      const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (pix0 + e < a.M);   // (no branches)
+      okB |= ok ? (1u << e) : 0u;
+      S.rb[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? b_off + (unsigned)(e * a.Cin) * 2u : OOB, soff_b, 0);
+      const bool we = ow + 1 == a.W;
+      ow = we ? 0 : ow + 1;
+      oh = we ? (oh + 1 == a.H ? 0 : oh + 1) : oh;
     }
+    S.okB = okB;
+  };
+  // dword j of a 16-byte load holds channels 2j (low half) and 2j+1 of one pixel; a store takes PG pixels of one channel
+  auto put = [&](__bf16* dst, unsigned d0, unsigned d1, bool four) {
+    if (four) *reinterpret_cast<u32x2*>(dst) = u32x2{d0, d1};
+    else *reinterpret_cast<unsigned*>(dst) = d0;
+  };
+  // one of the 16 stores of a tile: piece 0..7 = channel `piece` of this thread's dy chunk, 8..15 = of its `in` chunk
+  auto store_piece = [&](const Stage& S, int buf, int piece) {
+    __bf16* Ab = As + buf * BM * KTW + a_st;
+    __bf16* Bb = Bs + buf * BN * KTW + b_st;
+    const int j = (piece & 7) >> 1, hl = piece & 1;
+    if (piece < 8) {
+        const unsigned sel = hl ? 0x07060302u : 0x05040100u;
+        const unsigned d0 = __builtin_amdgcn_perm(S.ra[1][j], S.ra[0][j], sel);
+        const unsigned d1 = PGA == 4 ? __builtin_amdgcn_perm(S.ra[PGA - 1][j], S.ra[PGA - 2][j], sel) : 0u;
+        put(Ab + (2 * j + hl) * KTW, d0, d1, PGA == 4);
+    } else {
+        unsigned d0, d1 = 0u;
+        if (IN_BN) {
+          // the saved tensor is the raw convolution output: BN + ReLU on the way; padding stays 0 AFTER the transform
+          float v[PGB];
+#pragma unroll
+          for (int e = 0; e < PGB; ++e) {
+            const float x = __builtin_bit_cast(float, hl ? (S.rb[e][j] & 0xffff0000u) : (S.rb[e][j] << 16));
+            v[e] = ((S.okB >> e) & 1u) ? fmaxf(fmaf(x, sc8[2 * j + hl], sh8[2 * j + hl]), 0.f) : 0.f;
+          }
+          d0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+          if (PGB == 4) d1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[PGB - 2], v[PGB - 1]}, bf16x2));
+        } else {
+          const unsigned sel = hl ? 0x07060302u : 0x05040100u;
+          d0 = __builtin_amdgcn_perm(S.rb[1][j], S.rb[0][j], sel);
+          if (PGB == 4) d1 = __builtin_amdgcn_perm(S.rb[PGB - 1][j], S.rb[PGB - 2][j], sel);
+        }
+        put(Bb + (2 * j + hl) * KTW, d0, d1, PGB == 4);
+    }
+  };
+  auto store_tile = [&](const Stage& S, int buf) {
+#pragma unroll
+    for (int piece = 0; piece < 16; ++piece) store_piece(S, buf, piece);
+  };
+  // The MFMAs of tile kt with the 16 stores of tile kt+1 spread between them (16 / (4 TM TN) stores behind each MFMA):
+  // with the phases kept apart (loads | MFMAs | stores, one sched_barrier between) the ablation bits showed their times
+  // ADD UP (246 us fixed + 332 MFMA + 360 loads + 389 staging against 1196 measured for the MNIST launches) - two
+  // workgroups per CU do not interleave by themselves.
+  constexpr int NM = 4 * TM * TN, PER = 16 / NM;
+  auto iteration = [&](int kt, const Stage& Sst, Stage& Sld, auto store) {
+    constexpr bool ST = decltype(store)::value;   // (compile-time: a branch around every store would split the schedule)
+    const int cur = kt & 1;
+    if (ST) load_tile(kt + 2, Sld);
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* Ab = As + cur * BM * KTW;
+    const __bf16* Bb = Bs + cur * BN * KTW;
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + a_rd[im] + ((2 * ks) ^ a_sw[im]) * 8);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + b_rd[in] + ((2 * ks) ^ b_sw[in]) * 8);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
+          if (ST) {
+            const int m = (ks * TM + im) * TN + in;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) store_piece(Sst, cur ^ 1, m * PER + q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+  };
+  if (nk > 0) {
+    load_tile(0, S0);
+    load_tile(1, S1);
+    store_tile(S0, 0);
+  }
+  __syncthreads();
+  // every iteration but the last stores the next tile (and requests the one after it: the tail re-loads the last tile)
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    iteration(kt, S1, S0, std::true_type{});
+    iteration(kt + 1, S0, S1, std::true_type{});
+  }
+  if (kt + 2 == nk) {
+    iteration(kt, S1, S0, std::true_type{});
+    iteration(kt + 1, S0, S1, std::false_type{});
+  } else if (kt < nk) {
+    iteration(kt, S1, S0, std::false_type{});
   }
 
   float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
@@ -615,6 +835,31 @@ static int launch_wgrad_bf16(const WgradArgs& a, bool in_bn, hipStream_t st) {
   return 0;
 }
 
+// bf16-storage form (conv3x3_wgrad_bf16s_kernel); tdx_tune_set("bf16_wgrad_swz", 0) goes back to the IO16 variant above
+int g_tdx_wgrad_bf16s = 1;
+template <int BM, int BN>
+static int launch_wgrad_bf16s(const WgradArgs& a, bool in_bn, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * KTW * sizeof(__bf16);   // 80 KB for 128 x 128: two workgroups fill the CU's 160 KB
+  dim3 grid((unsigned)(((int64_t)a.groups + 7) / 8 * 72));
+#define TDX_LAUNCH_WG(INBN)                                                                          \
+  do {                                                                                               \
+    auto kern = conv3x3_wgrad_bf16s_kernel<BM, BN, INBN>;                                            \
+    static bool attr_set = false;                                                                    \
+    if (lds > 65536 && !attr_set) {                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 256, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (in_bn) TDX_LAUNCH_WG(true);
+  else TDX_LAUNCH_WG(false);
+#undef TDX_LAUNCH_WG
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* dw_slabs, int B, int H,
                                       int W, int cin, int cout, int flags, const float* in_scale,
                                       const float* in_shift, tdx_stream_t stream) {
@@ -640,7 +885,9 @@ extern "C" int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float
   a.groups = a.tilesCi * a.tilesCo * splits;
   a.adv_q = 0; a.adv_s = 0; a.dbg = tdx_conv_dbg_get();
   hipStream_t st = to_stream(stream);
-#define TDX_WG(BM_, BN_) (io16 ? launch_wgrad_bf16<BM_, BN_, true>(a, in_bn, st) : launch_wgrad_bf16<BM_, BN_, false>(a, in_bn, st))
+#define TDX_WG(BM_, BN_)                                                                        \
+  (io16 ? (g_tdx_wgrad_bf16s ? launch_wgrad_bf16s<BM_, BN_>(a, in_bn, st) : launch_wgrad_bf16<BM_, BN_, true>(a, in_bn, st)) \
+        : launch_wgrad_bf16<BM_, BN_, false>(a, in_bn, st))
   if (bm == 128 && bn == 128) return TDX_WG(128, 128);
   if (bm == 128 && bn == 64) return TDX_WG(128, 64);
   if (bm == 64 && bn == 128) return TDX_WG(64, 128);

@@ -24,6 +24,8 @@ DBG = int(os.environ.get("TDX_CONV_DBG", "0"))
 NO_REDUCE = os.environ.get("TDX_NO_REDUCE") == "1"
 if DBG:
     check(lib.tdx_tune_set(b"conv_dbg", DBG))
+if "TDX_WGRAD_SWZ" in os.environ:   # 0: the round-2 weight-gradient staging
+    check(lib.tdx_tune_set(b"bf16_wgrad_swz", int(os.environ["TDX_WGRAD_SWZ"])))
 st = torch.cuda.current_stream().cuda_stream
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for cin, cout, H, in_bn in units:
