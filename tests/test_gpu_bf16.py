@@ -118,6 +118,86 @@ def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
     assert rel_err(dw, ref_dw) < 2e-5
 
 
+# bf16-STORAGE entry points (tdx_conv3x3_fwd_bf16_io / tdx_conv3x3_wgrad_bf16_io, io16 = 1: activations and activation
+# gradients are bf16 tensors), every kernel variant the tuning knobs select:
+#   default  nine-tap weight gradient (conv3x3_wgrad9_bf16_kernel), 128-row forward / input-gradient kernel
+#   ring     + the 256-row DMA ring forward kernel where M % 256 == 0 (off by default: slower inside the step)
+#   per_tap  one workgroup per tap with the swizzled transposing stage (conv3x3_wgrad_bf16s_kernel)
+#   round2   the round-2 staging of the per-tap kernel
+IO16_VARIANTS = {"default": {}, "ring": {"bf16_ring": 1}, "per_tap": {"bf16_wgrad9": 0},
+                 "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}}
+IO16_CASES = [
+    # B, H, cin, cout, in_bn: M % 256 == 0 (ring) and ragged M; 4x4 .. 64x64 maps (the padded-slot ring of the nine-tap
+    # kernel: 64 slots span 2.5 samples at 4x4, its halo 4 blocks at 64x64); 64- and 128-wide tiles; BN+ReLU on load
+    (16, 28, 64, 128, 0), (16, 28, 128, 128, 1), (3, 14, 128, 256, 0), (16, 4, 512, 512, 1), (5, 7, 256, 512, 0),
+    (4, 8, 1024, 256, 0), (1, 64, 64, 64, 1), (2, 32, 192, 64, 0), (33, 8, 128, 128, 1), (4, 16, 384, 128, 0),
+]
+
+
+@pytest.mark.parametrize("variant", list(IO16_VARIANTS))
+@pytest.mark.parametrize("B,H,cin,cout,in_bn", IO16_CASES)
+def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
+    lib, check = tdx.lib, tdx.check
+    knobs = IO16_VARIANTS[variant]
+    g = torch.Generator().manual_seed(B * 1000 + H + cin)
+    x = torch.randn(B, cin, H, H, generator=g).bfloat16()
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(B, cout, H, H, generator=g).bfloat16()
+    isc, ish = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    # host arithmetic: the tensors ARE bf16; BN + ReLU on load is an fp32 fma rounded to bf16; exact products, fp64 sums
+    a = x.float()
+    if in_bn:
+        a = F.relu(torch.addcmul(ish.view(1, -1, 1, 1), a, isc.view(1, -1, 1, 1))).bfloat16().float()
+    a = a.double().requires_grad_(True)
+    wr = bf16_round(w).requires_grad_(True)
+    ref = F.conv2d(a, wr, b.double(), padding=1)
+    ref_dw, = torch.autograd.grad(ref, wr, dy.double(), retain_graph=True)
+    ref_dx, = torch.autograd.grad(ref, a, dy.double())
+    wf16 = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device="cuda")
+    wg16 = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device="cuda")
+    check(lib.tdx_pack_conv3x3_bf16(w.cuda().contiguous().data_ptr(), wf16.data_ptr(), wg16.data_ptr(), cout, cin, st()))
+    xin, gd = nhwc(x).cuda(), nhwc(dy).cuda()
+    iscd, ishd, bd = isc.cuda(), ish.cuda(), b.cuda()
+    scp, shp = (iscd.data_ptr(), ishd.data_ptr()) if in_bn else (None, None)
+    M = B * H * H
+    rows = lib.tdx_conv3x3_bf16_stat_tile_rows()
+    tiles = -(-M // rows)
+    out = torch.full((B, H, H, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
+    gin = torch.full((B, H, H, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)
+    slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    try:
+        for k, v in knobs.items():
+            check(lib.tdx_tune_set(k.encode(), v))
+        check(lib.tdx_conv3x3_fwd_bf16_io(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin, cout,
+                                          4 | (1 if in_bn else 0), scp, shp, None, None, stats.data_ptr(), 1, st()))
+        check(lib.tdx_conv3x3_fwd_bf16_io(gd.data_ptr(), wg16.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                          None, None, None, None, None, 1, st()))
+        check(lib.tdx_conv3x3_wgrad_bf16_io(xin.data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout,
+                                            1 if in_bn else 0, scp, shp, 1, st()))
+        check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st()))
+        torch.cuda.synchronize()
+    finally:
+        for k in knobs:   # back to the defaults (bf16_ring 0, the others 1)
+            check(lib.tdx_tune_set(k.encode(), 0 if k == "bf16_ring" else 1))
+    # outputs are rounded to bf16 once: 2^-9 relative per element at most
+    assert torch.isfinite(out.float()).all() and torch.isfinite(gin.float()).all()
+    assert rel_err(nchw(out.float()), ref.detach()) < 3e-3
+    assert (nchw(out.float()).double().cpu() - ref.detach()).abs().max() <= 2.0 ** -8 * ref.detach().abs().max() + 1e-6
+    assert rel_err(nchw(gin.float()), ref_dx) < 3e-3
+    # the statistics partials come from the fp32 accumulators, not from the rounded output
+    flat = ref.detach().permute(0, 2, 3, 1).reshape(-1, cout)
+    for ti in range(tiles):
+        blk = flat[ti * rows:(ti + 1) * rows]
+        assert torch.allclose(stats[ti, 0].double().cpu(), blk.sum(0), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(stats[ti, 1].double().cpu(), (blk - blk.mean(0)).pow(2).sum(0), rtol=1e-4, atol=2e-3)
+    # the weight gradient is fp32 all the way: accumulation order only
+    assert rel_err(dw, ref_dw) < 2e-5
+
+
 def test_bf16_conv_bn_relu_on_load_and_fused_epilogue(tdx):
     """BN+ReLU of the producing layer applied while staging (forward and weight gradient) and the
     inference epilogue relu((acc + bias) * scale + shift)."""

@@ -209,6 +209,217 @@ conv3x3_bf16_kernel(ConvArgs a) {
                                     tid);
 }
 
+// ------------------------------------------------------------- forward / input gradient, ring (round 3)
+// The bf16-storage forward and input-gradient GEMM for row counts that are a multiple of 256.  The kernel above keeps
+// the shape of the fp32 one (128 x 128 tile, four waves, two workgroups per CU, register staging); at the bf16 matrix
+// rate that shape is bound by everything except the matrix core - per K-tile and CU the loads take the L1 1024 cycles
+// (64 KB at 64 B/clk), the ds_write_b128 staging another ~800, the operand reads 512, the MFMAs 1024, and the ablation
+// bits showed the four add up instead of overlapping (tools/gpu_bf16_layers.py: 3300 cycles per K-tile).  Here:
+//   * 256 x BN tile, eight waves (4 x 2, 64 x BN/2 each), one workgroup per CU: 48 KB of operands per K-tile for
+//     twice the MFMAs of the old tile (87 FLOP per byte from L1 instead of 64);
+//   * weights and raw inputs go global -> LDS by DMA (buffer_load ... lds, 16 B per lane): no staging registers, no
+//     ds_write; a BN+ReLU input still passes through registers (16-byte loads, transform, ds_write_b128);
+//   * three LDS stages: the DMA of tile kt+2 is issued when tile kt starts, two K-tiles of MFMAs ahead of its use, and
+//     ONE barrier per K-tile - a counted s_waitcnt vmcnt in front of a raw s_barrier, because the workgroup-release
+//     fence inside __syncthreads() drains every outstanding DMA;
+//   * 128-byte rows, 16-byte chunk index XOR (row >> 1) & 7: the lane-linear DMA image and the ds_read_b128 operand
+//     reads are both conflict-free.
+// The epilogue is conv_epilogue<128, BN> run by each half of the workgroup on its 128 rows (statistics partials per 128
+// rows, as bn_finalize expects).
+template <int BN, bool IN_BN, int EPI>
+__global__ void __launch_bounds__(512)
+conv3x3_bf16_ring_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (address-space casts and s_waitcnt asm: device pass only)
+  constexpr int BM = 256, NST = 3;
+  constexpr int TM = 2, TN = BN / 64, WTN = BN / 2;
+  constexpr int BJ = BN / 64;                      // weight DMA instructions per wave and K-tile (8 rows x 128 B each)
+  constexpr int A_ST = BM * 64, B_ST = BN * 64;    // elements per stage
+  constexpr int STAGE = A_ST + B_ST;
+  constexpr int NV = IN_BN ? BJ + 4 : BJ + 4;      // VMEM instructions per thread and K-tile (DMA + register loads)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* ring = reinterpret_cast<__bf16*>(smem_raw);                       // [NST][A: 256 x 64 | B: BN x 64]
+  float* ssc = reinterpret_cast<float*>(smem_raw + NST * STAGE * 2);       // IN_BN: scale[Cin] | shift[Cin]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;   // (the launcher guarantees M % 256 == 0: no ragged tile)
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W;
+
+  const int neg = (a.W + 1) * a.Cin;
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(a.in)) - (int64_t)neg * 2, 0,
+      (int)(((int64_t)a.M * a.Cin + 2 * neg) * 2), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.Cout * 9 * a.Cin * 2, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- staging maps.  DMA: instruction i of wave w covers tile rows (i*8 + w)*8 .. +7, lane L -> row + (L >> 3),
+  // stored chunk L & 7, which holds logical chunk (L & 7) ^ x(row).  Register path (IN_BN): thread -> logical chunk
+  // tid & 7 of rows (tid >> 3) + 64 i.
+  const int drow = lane >> 3, dch = lane & 7;
+  unsigned a_off[4], a_taps[4];
+  int a_lds[4];   // IN_BN: byte offset of the thread's 16-byte store inside the A stage
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = IN_BN ? (tid >> 3) + 64 * i : (i * 8 + wave) * 8 + drow;
+    const int x = (r >> 1) & 7;
+    const int p = m0 + r;
+    const int rr = p % HW, oh = rr / a.W, ow = rr % a.W;
+    unsigned taps = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) taps |= 1u << t;
+    }
+    a_taps[i] = taps;
+    const int chunk = IN_BN ? (tid & 7) : (dch ^ x);
+    a_off[i] = (unsigned)(p * a.Cin + chunk * 8) * 2u;
+    a_lds[i] = r * 128 + (((tid & 7) ^ x) << 4);
+  }
+  unsigned w_off[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int r = (j * 8 + wave) * 8 + drow;
+    w_off[j] = (unsigned)((n0 + r) * 9 * a.Cin + ((dch ^ ((r >> 1) & 7)) << 3)) * 2u;
+  }
+  if (IN_BN) {
+    for (int c = tid; c < a.Cin; c += 512) {
+      ssc[c] = a.in_scale[c];
+      ssc[a.Cin + c] = a.in_shift[c];
+    }
+  }
+
+  // ---- operand reads: row wm*64 + im*32 + l31 (A) / wn*WTN + in*32 + l31 (B), chunk (2 ks + half) ^ x, x from l31 only
+  const int x31 = (l31 >> 1) & 7;
+  const int a_rd = (wm * 64 + l31) * 128, b_rd = A_ST * 2 + (wn * WTN + l31) * 128;   // bytes inside a stage
+  int frag_pos[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) frag_pos[ks] = ((2 * ks + half) ^ x31) << 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int im = 0; im < TM; ++im)
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
+
+  const int nk = 9 * (a.Cin / KT);
+  struct Regs {
+    u32x4 ra[4];
+    unsigned ok;
+    int cb;   // channel block of the tile (scale / shift look-up)
+  };
+  Regs R0, R1;
+  // every call issues exactly NV VMEM instructions per thread (requests past the last tile repeat it and are never read)
+  auto issue = [&](int kt, int st, Regs& R) {
+    const int kn = min(kt, nk - 1);
+    const int cblk = kn / 9, tap = kn - cblk * 9;
+    const unsigned soff_in = (unsigned)(((tap / 3) * a.W + (tap % 3)) * a.Cin + cblk * KT) * 2u;
+    const unsigned soff_w = (unsigned)(tap * a.Cin + cblk * KT) * 2u;
+    unsigned char* sb = smem_raw + st * (STAGE * 2);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + A_ST * 2 + (j * 8 + wave) * 1024), 16, w_off[j], soff_w, 0, 0);
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool v = (a_taps[i] >> tap) & 1u;
+      if (IN_BN) {
+        ok |= v ? (1u << i) : 0u;
+        R.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, v ? a_off[i] : OOB, soff_in, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(sb + (i * 8 + wave) * 1024), 16, v ? a_off[i] : OOB, soff_in, 0, 0);
+      }
+    }
+    R.ok = ok;
+    R.cb = cblk;
+  };
+  // IN_BN: piece i of a tile held in registers: BN + ReLU on eight channels, padding stays 0 AFTER the transform
+  auto put_piece = [&](const Regs& R, int st, int i) {
+    const float* sc = ssc + R.cb * KT + (tid & 7) * 8;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sc + a.Cin), h1 = *reinterpret_cast<const f32x4*>(sc + a.Cin + 4);
+    const bf16x8 h = __builtin_bit_cast(bf16x8, R.ra[i]);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (__bf16)fmaxf(fmaf((float)h[e], s0[e], h0[e]), 0.f);
+      o[e + 4] = (__bf16)fmaxf(fmaf((float)h[e + 4], s1[e], h1[e]), 0.f);
+    }
+    u32x4 raw = __builtin_bit_cast(u32x4, o);
+    if (!((R.ok >> i) & 1u)) raw = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(smem_raw + st * (STAGE * 2) + a_lds[i]) = raw;
+  };
+  bf16x8 af[2][TM], bf[2][TN];
+  auto read_frags = [&](int st, int ks, int slot) {
+    const unsigned char* sb = smem_raw + st * (STAGE * 2);
+#pragma unroll
+    for (int im = 0; im < TM; ++im) af[slot][im] = *reinterpret_cast<const bf16x8*>(sb + a_rd + im * 32 * 128 + frag_pos[ks]);
+#pragma unroll
+    for (int in = 0; in < TN; ++in) bf[slot][in] = *reinterpret_cast<const bf16x8*>(sb + b_rd + in * 32 * 128 + frag_pos[ks]);
+  };
+  // top of iteration kt: this thread's loads of tile kt have landed when only the NV of tile kt+1 are outstanding; the
+  // barrier then says the same of every wave, and that all of them are done with the stage tile kt+2 goes to
+#define TDX_RING_BARRIER() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NV) : "memory")
+  auto iteration = [&](int kt, int st, Regs& Rnext, Regs& Rfree) {
+    TDX_RING_BARRIER();
+    int st2 = st + 2; st2 = st2 >= NST ? st2 - NST : st2;
+    int st1 = st + 1; st1 = st1 >= NST ? st1 - NST : st1;
+    if (!(a.dbg & 64)) issue(kt + 2, st2, Rfree);   // (ablation bits, tools/gpu_bf16_layers.py: 64 no loads, 16 no MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.dbg & 16) return;
+    read_frags(st, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+        read_frags(st, ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);   // the reads of k-step ks+1 are issued before the MFMAs of k-step ks
+      }
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][im], bf[ks & 1][in], acc[im][in], 0, 0, 0);
+      if (IN_BN) put_piece(Rnext, st1, ks);   // tile kt+1 (loaded an iteration ago) -> its stage, behind this k-step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  issue(0, 0, R0);
+  issue(1, 1, R1);
+  if (IN_BN) {
+    __syncthreads();   // the scale / shift copy
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put_piece(R0, 0, i);
+  }
+  {
+    int st = 0;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      iteration(kt, st, R1, R0);       // tile kt+1 is in R1; tile kt+2 -> R0
+      st = st + 1 == NST ? 0 : st + 1;
+      iteration(kt + 1, st, R0, R1);
+      st = st + 1 == NST ? 0 : st + 1;
+    }
+    if (kt < nk) iteration(kt, st, R1, R0);   // (nk = 9 Cin / 64 is odd for odd Cin / 64)
+  }
+#undef TDX_RING_BARRIER
+  // the tail requests are still in flight towards LDS: drain them before the epilogue re-uses the tile buffers
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (a.dbg & 128) return;   // (ablation: no epilogue)
+  const int h = wm >> 1;   // which 128-row half of the tile this wave belongs to
+  conv_epilogue<128, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw + h * 40960), tile_m * 2 + h, m0 + 128 * h, n0,
+                                     wm & 1, wn, l31, half, tid & 255);
+#endif
+}
+
 // --------------------------------------------------------------------------------------------- wgrad
 // dW[co][tap][ci] = sum_p dy[p][co] * in[p + tap][ci].  Both operands are pixel-major in memory while
 // the MFMA wants 8 consecutive k (pixels) of one row (channel) per lane, so the tiles are transposed
@@ -689,6 +900,235 @@ conv3x3_wgrad_bf16s_kernel(WgradArgs a) {
       }
 }
 
+// ------------------------------------------------------------ wgrad, nine taps per workgroup (round 3)
+// The kernels above give every tap its own workgroup: the dy tile is staged nine times and the input tile nine times
+// shifted, 64 FLOP per byte that crosses the L1 - and every bf16 launch of this library settles at 7-10 TB/s of L1
+// fills, whatever its kernel does in between.  Here ONE workgroup owns a 64 x 64 (co, ci) tile for ALL nine taps of a
+// pixel range: 288 FLOP per byte.  What makes that possible:
+//   * both operands stay in LDS the way they lie in memory, [pixel][channel] rows of 128 bytes, filled by LDS-DMA
+//     (16 B per lane, no registers), and the MFMA operands are read with ds_read_b64_tr_b16 (the gfx950 transposing
+//     read: a 16-lane group fetches 4 rows x 16 channels and each lane receives one channel's four pixels);
+//   * a tap is then a ROW OFFSET of the input image, if the pixel index is made one-dimensional: K runs over SLOTS of a
+//     padded image, (H+1) x (W+1) per sample with a zero column after every row and a zero row after every sample,
+//     slot = (n (H+1) + oh)(W+1) + ow, so that the (dh, dw) neighbour of a slot is slot + dh (W+1) + dw and every
+//     out-of-image neighbour lands on a zero slot.  dy rows of pad slots are zero too (OOB DMA), so they add nothing;
+//   * the input rows live in a ring of 64-slot blocks (each block is fetched once; the halo of the next K-tile is the
+//     body of this one), with the first 64 rows mirrored behind the last so that a 64-row window never wraps.
+// K inflates by (H+1)(W+1)/(HW): 7 % at 28 x 28, 31 % at 7 x 7 (where there is little K anyway).
+// Per K-tile and wave: 36 MFMAs (one 32 x 32 tile per tap), 8 + 72 transposing reads, 4 DMA instructions.
+template <bool IN_BN>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wgrad9_bf16_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // LDS: A [2][64 rows][128 B] | B ring [R + 64 rows][128 B]
+  const int PW = a.W + 1, PH = a.H + 1, PP = PH * PW;
+  const int HALOB = (PW + 1 + 63) / 64 * 64;          // block-aligned halo in front of the first tile
+  const int NB = (HALOB + 64 + PW) / 64;               // tile t reads blocks t .. t+NB
+  const int NBLK = NB + 2;                              // + the block in flight
+  const int R = NBLK * 64;
+  unsigned char* Abuf = smem_raw;
+  unsigned char* Bring = smem_raw + 2 * 64 * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // workgroup -> (pixel chunk, tile): the tiles of one chunk share an XCD (they read the same pixels)
+  const int tiles = a.tilesCo * a.tilesCi;
+  const int L = blockIdx.x;
+  const int split = (L / (8 * tiles)) * 8 + (L % 8);
+  const int tl = (L / 8) % tiles;
+  if (split * a.chunk >= a.M) return;
+  const int co0 = (tl / a.tilesCi) * 64, ci0 = (tl % a.tilesCi) * 64;
+  const int HW = a.H * a.W;
+  const int p_lo = split * a.chunk, p_hi = min(p_lo + a.chunk, a.M);
+  auto slot_of = [&](int p) { const int n = p / HW, r = p - n * HW; const int oh = r / a.W; return n * PP + oh * PW + (r - oh * a.W); };
+  const int s_lo = slot_of(p_lo), s_hi = slot_of(p_hi - 1) + 1;   // dy rows outside [s_lo, s_hi) are zero for this workgroup
+  const int nk = (s_hi - s_lo + 63) / 64;
+
+  const auto rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)((int64_t)a.M * a.Cout * 2), 0x00020000);
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)a.M * a.Cin * 2), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- staging: instruction i of wave w covers local rows (i*4 + w)*8 .. +7; lane -> row + (lane >> 3), stored chunk
+  // lane & 7 = logical chunk ^ swz(row), swz(r) = ((r >> 1) & 1) << 2.  IN_BN register path: logical chunk tid & 7 of
+  // rows (tid >> 3) + 32 i.
+  struct Pos { int n, oh, ow; };
+  auto pos_of = [&](int slot) {   // slot may be negative (halo in front of the tensor): shift by 8 samples
+    const int s8 = slot + 8 * PP;
+    Pos q; q.n = s8 / PP - 8; const int r = s8 % PP; q.oh = r / PW; q.ow = r - q.oh * PW; return q;
+  };
+  const int dn = 64 / PP, d_oh = (64 % PP) / PW, d_ow = (64 % PP) % PW;   // 64 slots further
+  auto advance = [&](Pos& q) {
+    int ow = q.ow + d_ow; const bool c = ow >= PW; ow = c ? ow - PW : ow;
+    int oh = q.oh + d_oh + (c ? 1 : 0); const bool c2 = oh >= PH; oh = c2 ? oh - PH : oh;
+    q.ow = ow; q.oh = oh; q.n += dn + (c2 ? 1 : 0);
+  };
+  const int nB = a.M / HW;
+  auto pixel = [&](const Pos& q, bool& real) {
+    real = ((unsigned)q.n < (unsigned)nB) & (q.oh < a.H) & (q.ow < a.W);
+    return (q.n * a.H + q.oh) * a.W + q.ow;
+  };
+  int rowA[2], rowB[2];
+  Pos pa[2], pb[2];
+  unsigned cha[2], chb[2];   // byte offset of this lane's 16-byte chunk inside a pixel row
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    rowA[i] = (i * 4 + wave) * 8 + (lane >> 3);
+    rowB[i] = IN_BN ? (tid >> 3) + 32 * i : rowA[i];
+    pa[i] = pos_of(s_lo + rowA[i]);
+    pb[i] = pos_of(s_lo - HALOB + rowB[i]);
+    cha[i] = (unsigned)(co0 + (((lane & 7) ^ (((rowA[i] >> 1) & 1) << 2)) << 3)) * 2u;
+    chb[i] = (unsigned)(ci0 + ((IN_BN ? (tid & 7) : ((lane & 7) ^ (((rowB[i] >> 1) & 1) << 2))) << 3)) * 2u;
+  }
+  float sc8[8], sh8[8];
+  if (IN_BN) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      sc8[c] = a.in_scale[ci0 + (tid & 7) * 8 + c];
+      sh8[c] = a.in_shift[ci0 + (tid & 7) * 8 + c];
+    }
+  }
+  // tile t of dy -> Abuf[t & 1]; the slot state advances with every call
+  int a_slot0 = s_lo;
+  auto issue_A = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bool real;
+      const int p = pixel(pa[i], real);
+      const int s = a_slot0 + rowA[i];
+      real = real & (s < s_hi);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (lds_ptr_t)(Abuf + buf * 8192 + (i * 4 + wave) * 1024), 16,
+                                               real ? (unsigned)p * (unsigned)a.Cout * 2u + cha[i] : OOB, 0, 0, 0);
+      advance(pa[i]);
+    }
+    a_slot0 += 64;
+  };
+  // block b of the input -> ring rows (b mod NBLK)*64 .. +63 (+ the mirror behind the ring for the first 64 rows)
+  struct BRegs { u32x4 r[2]; unsigned ok; };
+  int b_blk = 0;   // ring position (block index mod NBLK) of the next block
+  auto issue_B = [&](BRegs& Rg) {
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bool real;
+      const int p = pixel(pb[i], real);
+      const unsigned off = real ? (unsigned)p * (unsigned)a.Cin * 2u + chb[i] : OOB;
+      if (IN_BN) {
+        ok |= real ? (1u << i) : 0u;
+        Rg.r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, off, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(Bring + b_blk * 8192 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+        if (b_blk == 0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(Bring + R * 128 + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+      }
+      advance(pb[i]);
+    }
+    Rg.ok = ok;
+    if (!IN_BN) b_blk = b_blk + 1 == NBLK ? 0 : b_blk + 1;
+  };
+  // IN_BN: the block held in registers -> BN + ReLU -> ring (pad slots stay 0 AFTER the transform)
+  auto put_B = [&](const BRegs& Rg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 h = __builtin_bit_cast(bf16x8, Rg.r[i]);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(fmaf((float)h[e], sc8[e], sh8[e]), 0.f);
+      u32x4 raw = __builtin_bit_cast(u32x4, o);
+      if (!((Rg.ok >> i) & 1u)) raw = u32x4{0u, 0u, 0u, 0u};
+      const int row = rowB[i];
+      const int off = row * 128 + (((tid & 7) ^ (((row >> 1) & 1) << 2)) << 4);
+      *reinterpret_cast<u32x4*>(Bring + b_blk * 8192 + off) = raw;
+      if (b_blk == 0) *reinterpret_cast<u32x4*>(Bring + R * 128 + off) = raw;
+    }
+    b_blk = b_blk + 1 == NBLK ? 0 : b_blk + 1;
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- transposing operand reads (cdna_hip_programming.md T10; tools/micro/tr_read_probe.hip checks this addressing):
+  // lane = 16 g + 4 q + pp supplies row q of its group's 4 x 16 block, channels 4 pp .. 4 pp + 3, and receives channel
+  // 16 (g & 1) + (lane & 15) of the four rows.  A k-step is 16 slots: lanes 0-31 take slots 0-7 of it, lanes 32-63 slots
+  // 8-15, two reads of four rows each.  Row offsets that are multiples of 4 keep bit 1 of the row, i.e. the swizzle, so
+  // the eight reads of a (tile, tap) share one address register and differ in the immediate offset.
+  typedef __bf16 bf16x4v __attribute__((__vector_size__(4 * sizeof(__bf16))));
+  typedef __attribute__((address_space(3))) bf16x4v* lds_v4;
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const int lrow = 8 * (g >> 1) + q4;
+  const int chA = wm * 4 + 2 * (g & 1) + (pp >> 1), chBf = wn * 4 + 2 * (g & 1) + (pp >> 1);
+  const int subb = 8 * (pp & 1);
+  auto frag = [&](const unsigned char* base, int ks) -> bf16x8 {
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + (16 * ks) * 128));
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + (16 * ks + 4) * 128));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  BRegs Rg;
+  // prologue: dy tile 0 and input blocks 0 .. NB
+  issue_A(0);
+  for (int b = 0; b <= NB; ++b) {
+    issue_B(Rg);
+    if (IN_BN) put_B(Rg);
+  }
+  int tbase = HALOB % R;   // ring row of slot s_lo + 64 t
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();   // tile t and its blocks have landed (the fence drains the DMA); tile t-1 has been read by every wave
+    const bool more = t + 1 < nk && !(a.dbg & 64);   // (ablation bits of tools/gpu_bf16_layers.py: 64 no loads, 16 no MFMAs / reads)
+    if (more) {
+      issue_A((t + 1) & 1);
+      issue_B(Rg);
+    }
+    if (a.dbg & 16) continue;
+    const unsigned char* Ab = Abuf + (t & 1) * 8192 + lrow * 128 + ((chA ^ (((lrow >> 1) & 1) << 2)) << 4) + subb;
+    bf16x8 af[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) af[ks] = frag(Ab, ks);
+    // the input operand of tap+1 (eight reads) is requested before the four MFMAs of tap: hipcc otherwise keeps two
+    // fragments in flight and every MFMA pair waits for its LDS round trip
+    bf16x8 bfr[2][4];
+    auto load_tap = [&](int tap, bf16x8 (&dst)[4]) {
+      int r0 = tbase + (tap / 3 - 1) * PW + (tap % 3 - 1);   // first ring row of this tap's 64-row window (uniform)
+      r0 = r0 < 0 ? r0 + R : (r0 >= R ? r0 - R : r0);
+      const int row = r0 + lrow;
+      const unsigned char* Bb = Bring + row * 128 + ((chBf ^ (((row >> 1) & 1) << 2)) << 4) + subb;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dst[ks] = frag(Bb, ks);
+    };
+    load_tap(0, bfr[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) load_tap(tap + 1, bfr[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[tap & 1][ks], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (IN_BN && more) put_B(Rg);
+    tbase = tbase + 64 >= R ? tbase + 64 - R : tbase + 64;
+  }
+
+  float* slab = a.slabs + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + wn * 32 + l31;
+      slab[((size_t)co * 9 + tap) * a.Cin + ci] = acc[tap][r];
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------ packing
 // OIHW fp32 -> bf16 forward pack [Cout][9][Cin] and dgrad pack [Cin][9 mirrored][Cout]; one launch for
 // all units of a network (TdxPackBatch, destinations reinterpreted as bf16)
@@ -772,6 +1212,43 @@ static int launch_bf16(const ConvArgs& a, int flags, hipStream_t st) {
   return 0;
 }
 
+// conv3x3_bf16_ring_kernel: 256-row tiles, 512 threads, three DMA stages (+ 8 KB for the BN scale / shift copy)
+// Off by default: isolated, the ring kernel is 6-9 % faster over the MNIST launches (forward 1109 -> 1043 us, input
+// gradient 955 -> 865), but one 155 KB workgroup per CU shares a CU with nothing, and inside the three-stream step it
+// measured SLOWER (MNIST bf16 4.50 vs 4.40 ms, LAION 64x64 10.29 vs 10.12).  tdx_tune_set("bf16_ring", 1) selects it.
+int g_tdx_bf16_ring = 0;
+template <int BN>
+static int launch_bf16_ring(const ConvArgs& a, int flags, hipStream_t st) {
+  const size_t lds = (size_t)3 * (256 + BN) * 64 * sizeof(__bf16) + 8192;
+  const int grid = (cdiv(a.M, 256) + 7) / 8 * 8 * a.tilesN;
+  const bool in_bn = flags & TDX_CONV_IN_BNRELU;
+  const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS : EPI_PLAIN;
+#define TDX_LAUNCH_RING(INBN, EPI_)                                                                  \
+  do {                                                                                               \
+    auto kern = conv3x3_bf16_ring_kernel<BN, INBN, EPI_>;                                            \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 512, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (in_bn) {
+    if (epi == EPI_BNRELU) TDX_LAUNCH_RING(true, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH_RING(true, EPI_STATS);
+    else TDX_LAUNCH_RING(true, EPI_PLAIN);
+  } else {
+    if (epi == EPI_BNRELU) TDX_LAUNCH_RING(false, EPI_BNRELU);
+    else if (epi == EPI_STATS) TDX_LAUNCH_RING(false, EPI_STATS);
+    else TDX_LAUNCH_RING(false, EPI_PLAIN);
+  }
+#undef TDX_LAUNCH_RING
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const float* bias, float* out,
                                     int B, int H, int W, int cin, int cout, int flags,
                                     const float* in_scale, const float* in_shift,
@@ -803,6 +1280,10 @@ extern "C" int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, co
   a.splits = 1; a.kt_per_split = 0; a.dbg = tdx_conv_dbg_get(); a.stamps = nullptr;
   a.out_bf16 = io16 ? 1 : 0;
   hipStream_t st = to_stream(stream);
+  if (io16 && g_tdx_bf16_ring && a.M % 256 == 0 && cin <= 1024) {
+    a.tilesN = cout % 128 == 0 ? cout / 128 : cout / 64;
+    return cout % 128 == 0 ? launch_bf16_ring<128>(a, flags, st) : launch_bf16_ring<64>(a, flags, st);
+  }
   // memory-bound: the widest column tile re-reads the input least often
   if (cout % 128 == 0) {
     a.tilesN = cout / 128;
@@ -860,6 +1341,35 @@ static int launch_wgrad_bf16s(const WgradArgs& a, bool in_bn, hipStream_t st) {
   return 0;
 }
 
+// conv3x3_wgrad9_bf16_kernel: one workgroup per (pixel chunk, 64 x 64 tile), all nine taps; same chunks and slabs as
+// the per-tap kernels (tdx_wgrad_plan), 2.25-4.5x fewer workgroups.  tdx_tune_set("bf16_wgrad9", 0) switches it off.
+int g_tdx_wgrad9 = 1;
+static int launch_wgrad9_bf16(WgradArgs a, int splits, bool in_bn, hipStream_t st) {
+  a.tilesCo = a.Cout / 64;
+  a.tilesCi = a.Cin / 64;
+  const int PW = a.W + 1;
+  const int HALOB = (PW + 1 + 63) / 64 * 64, NB = (HALOB + 64 + PW) / 64, R = (NB + 2) * 64;   // as in the kernel
+  const size_t lds = (size_t)2 * 64 * 128 + (size_t)(R + 64) * 128;
+  dim3 grid((unsigned)((splits + 7) / 8 * 8 * a.tilesCo * a.tilesCi));
+#define TDX_LAUNCH_WG9(INBN)                                                                         \
+  do {                                                                                               \
+    auto kern = conv3x3_wgrad9_bf16_kernel<INBN>;                                                    \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 98304);         \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 256, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (in_bn) TDX_LAUNCH_WG9(true);
+  else TDX_LAUNCH_WG9(false);
+#undef TDX_LAUNCH_WG9
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_conv3x3_wgrad_bf16(const float* in, const float* dy, float* dw_slabs, int B, int H,
                                       int W, int cin, int cout, int flags, const float* in_scale,
                                       const float* in_shift, tdx_stream_t stream) {
@@ -885,6 +1395,7 @@ extern "C" int tdx_conv3x3_wgrad_bf16_io(const void* in_, const void* dy_, float
   a.groups = a.tilesCi * a.tilesCo * splits;
   a.adv_q = 0; a.adv_s = 0; a.dbg = tdx_conv_dbg_get();
   hipStream_t st = to_stream(stream);
+  if (io16 && g_tdx_wgrad9 && W <= 95) return launch_wgrad9_bf16(a, splits, in_bn, st);   // (ring of <= 7 blocks: 96 KB of LDS)
 #define TDX_WG(BM_, BN_)                                                                        \
   (io16 ? (g_tdx_wgrad_bf16s ? launch_wgrad_bf16s<BM_, BN_>(a, in_bn, st) : launch_wgrad_bf16<BM_, BN_, true>(a, in_bn, st)) \
         : launch_wgrad_bf16<BM_, BN_, false>(a, in_bn, st))

@@ -13,6 +13,11 @@ dt = torch.float32 if os.environ.get("TDX_FP32") else torch.bfloat16
 if os.environ.get("TDX_BF16_STORAGE") is not None:   # 0: bf16 MFMA operands only, fp32 tensors (the round-2 form)
     from tiny_diffusion_amd._lib import lib
     assert lib.tdx_tune_set(b"bf16_storage", int(os.environ["TDX_BF16_STORAGE"])) == 0
+for knob in ("bf16_ring", "bf16_wgrad_swz"):   # TDX_TUNE_bf16_ring=0 ...: A/B of the round-3 bf16 kernels
+    v = os.environ.get("TDX_TUNE_" + knob)
+    if v is not None:
+        from tiny_diffusion_amd._lib import lib
+        assert lib.tdx_tune_set(knob.encode(), int(v)) == 0
 torch.manual_seed(0)
 if which == "mnist":
     from tiny_diffusion_amd.diffusion import ForwardProcess, NoiseModel
