@@ -643,7 +643,8 @@ def test_train_step_graph_capture_three_streams():
     eager, graph = out
     assert torch.equal(eager[0][1], graph[0][1]) and torch.equal(eager[0][2], graph[0][2])   # step 1 is eager in both
     assert torch.equal(eager[1][1], graph[1][1]), "first replayed step: gradients differ from the eager step"
-    assert (eager[1][2] - graph[1][2]).abs().max().item() <= 1e-9
+    # one fp32 ulp of a parameter (1.2e-7 at |p| ~ 1: the BatchNorm weights) is the most the two scalar paths can differ by
+    assert ((eager[1][2] - graph[1][2]).abs() <= 2.4e-7 * eager[1][2].abs().clamp_min(1.0)).all()
     assert np.allclose([r[0] for r in eager], [r[0] for r in graph], rtol=1e-4), ([r[0] for r in eager], [r[0] for r in graph])
 
 

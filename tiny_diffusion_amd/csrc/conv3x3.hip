@@ -738,6 +738,7 @@ static int g_wgrad_plan = 1;          // 0: round-1 targets; 1: the same, split 
                                       // 2: tile and rounds by a cost model (experiments: best isolated, worse inside the step)
 static int g_wgrad_rounds = 0;        // experiments: force that many rounds in pick_wgrad (0: cheapest by its cost model)
 #define TDX_CONV_OUT_BNBWD 8   /* internal flag: the epilogue emits BatchNorm-backward partial sums (ConvArgs::bw_*) */
+static int g_wgrad9_wgs = 0;          // bf16 mode: workgroups of the nine-tap kernel aimed at by the split (0: the per-tap plan's splits)
 static int g_wgrad_small = 1;         // 64x64 wgrad tiles for big-weight / few-pixel layers
 
 extern "C" int tdx_conv3x3_dgrad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W,
@@ -796,6 +797,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "bf16_wgrad_swz")) { g_tdx_wgrad_bf16s = value ? 1 : 0; return 0; }   // 0: the round-2 staging (8-way LDS store conflicts)
   if (!strcmp(key, "conv_stamp")) { g_conv_stamp = value; g_tdx_probe_stamp = value; return 0; }
   if (!strcmp(key, "wgrad_small")) { g_wgrad_small = value; return 0; }
+  if (!strcmp(key, "wgrad9_wgs")) { g_wgrad9_wgs = value > 0 ? value : 0; return 0; }
   if (!strcmp(key, "wgrad_plan")) { g_wgrad_plan = value; return 0; }
   if (!strcmp(key, "wgrad_rounds")) { g_wgrad_rounds = value; return 0; }
   if (!strcmp(key, "conv_dma")) { g_conv_dma = value; return 0; }
@@ -1654,6 +1656,8 @@ static WgradCfg pick_wgrad_legacy(int64_t M, int cin, int cout, bool bf16) {
     const int64_t two_rounds = 2 * 256 * (int64_t)lds_slots_per_cu(2 * 32 * (c.bm + c.bn) * 4);
     if (two_rounds / tiles >= 8) s = two_rounds / tiles;
   }
+  // bf16 mode with the nine-tap kernel (64 x 64 tiles, all taps in one workgroup): aim at g_wgrad9_wgs workgroups
+  if (bf16 && g_wgrad9_wgs > 0) s = g_wgrad9_wgs / ((int64_t)(cout / 64) * (cin / 64));
   int64_t smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;

@@ -133,11 +133,12 @@ conv3x3_bf16_kernel(ConvArgs a) {
     }
     S.ok = ok;
   };
-  auto store_tile = [&](const Stage& S, int buf) {
+  // piece 0 .. AI-1: one 16-byte (bf16 storage) / 8-byte row chunk of the input tile; AI .. AI+BI-1: of the weights
+  auto store_piece = [&](const Stage& S, int buf, int piece) {
     __bf16* Ab = As + buf * BM * KTP;
     __bf16* Bb = Bs + buf * BN * KTP;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
+    if (piece < AI) {
+      const int i = piece;
       if (IO16) {
         f32x4 raw = S.ra[i];   // eight bf16
         if (IN_BN) {
@@ -162,10 +163,51 @@ conv3x3_bf16_kernel(ConvArgs a) {
         }
         *reinterpret_cast<bf16x4*>(Ab + (a_row + ARW * i) * KTP + a_c4 * 4) = __builtin_convertvector(v, bf16x4);
       }
-    }
-#pragma unroll
-    for (int j = 0; j < BI; ++j)
+    } else {
+      const int j = piece - AI;
       *reinterpret_cast<f32x4*>(Bb + (b_row + 32 * j) * KTP + b_ch * 8) = S.rb[j];
+    }
+  };
+  auto store_tile = [&](const Stage& S, int buf) {
+#pragma unroll
+    for (int piece = 0; piece < AI + BI; ++piece) store_piece(S, buf, piece);
+  };
+  // Input-gradient launches (raw input, plain epilogue): the MFMAs of tile kt with the stores of tile kt+1 spread between
+  // them, as in conv3x3_wgrad_bf16s_kernel - 931 -> 862 us over the MNIST layers.  ST is a compile-time flag (a branch
+  // around every store would split the schedule).  The forward launches keep the phases apart: the same interleaving made
+  // them SLOWER (1072 -> 1255-1324 us, with and without the BN + ReLU transform between the MFMAs).  (A third register
+  // stage - the loads of tile kt+3 in flight too - measured no faster: the loop is not waiting for its loads.)
+  constexpr bool IL = !IN_BN && EPI == EPI_PLAIN;
+  constexpr int NM = 4 * TM * TN, NP = AI + BI;
+  auto iteration_il = [&](int kt, const Stage& Sst, Stage& Sld, auto store) {
+    constexpr bool ST = decltype(store)::value;
+    const int cur = kt & 1;
+    if (ST) load_tile(kt + 2, Sld);
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads at the top: hipcc otherwise sinks them
+    const __bf16* Ab = As + cur * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
+    const __bf16* Bb = Bs + cur * BN * KTP + (wn * WTN + l31) * KTP + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int im = 0; im < TM; ++im) af[im] = *reinterpret_cast<const bf16x8*>(Ab + im * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int in = 0; in < TN; ++in) bf[in] = *reinterpret_cast<const bf16x8*>(Bb + in * 32 * KTP + ks * 16);
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
+          if (ST) {
+            const int m = (ks * TM + im) * TN + in;   // store piece p behind MFMA m when p * NM / NP == m
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc)
+              if (pc * NM / NP == m) store_piece(Sst, cur ^ 1, pc);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
   };
   auto compute = [&](int buf) {
     const __bf16* Ab = As + buf * BM * KTP + (wm * WTM + l31) * KTP + half * 8;
@@ -184,9 +226,7 @@ conv3x3_bf16_kernel(ConvArgs a) {
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[im], bf[in], acc[im][in], 0, 0, 0);
     }
   };
-  // (a third register stage - the loads of tile kt+3 in flight too - measured no faster in bf16-storage mode: the loop
-  // is not waiting for its loads, see conv3x3_wgrad_bf16s_kernel)
-  auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {
+  auto iteration = [&](int kt, const Stage& Sst, Stage& Sld) {   // (a.dbg: ablation bits of tools/gpu_bf16_layers.py)
     const int cur = kt & 1;
     if (!(a.dbg & 64)) load_tile(kt + 2, Sld);   // (clamped at the end: a redundant re-load, never stored)
     __builtin_amdgcn_sched_barrier(0);      // keep the loads at the top: hipcc otherwise sinks them
@@ -199,12 +239,26 @@ conv3x3_bf16_kernel(ConvArgs a) {
   load_tile(1, S1);
   store_tile(S0, 0);
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    iteration(kt, S1, S0);       // S1 holds tile kt+1; tile kt+2 -> S0
-    iteration(kt + 1, S0, S1);   // S0 holds tile kt+2; tile kt+3 -> S1
+  if constexpr (IL) {
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+      iteration_il(kt, S1, S0, std::true_type{});       // S1 holds tile kt+1; tile kt+2 -> S0
+      iteration_il(kt + 1, S0, S1, std::true_type{});   // S0 holds tile kt+2; tile kt+3 -> S1
+    }
+    if (kt + 2 == nk) {
+      iteration_il(kt, S1, S0, std::true_type{});
+      iteration_il(kt + 1, S0, S1, std::false_type{});
+    } else if (kt < nk) {
+      iteration_il(kt, S1, S0, std::false_type{});
+    }
+  } else {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      iteration(kt, S1, S0);
+      iteration(kt + 1, S0, S1);
+    }
+    if (kt < nk) iteration(kt, S1, S0);
   }
-  if (kt < nk) iteration(kt, S1, S0);
   conv_epilogue<BM, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw), tile_m, m0, n0, wm, wn, l31, half,
                                     tid);
 }

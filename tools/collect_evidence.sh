@@ -19,6 +19,8 @@ run rocprofv3 --pmc MfmaUtil --output-format csv -d gpurun_out/${tag}_pmc_mfma -
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_train -- python3 bench.py --train-only --steps 30 --warmup 5 > gpurun_out/${tag}_train.json 2> gpurun_out/${tag}_train.err && echo train ok &&
 run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bench -- python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_bench.err && echo bench ok
 rc=$?
+# the bf16 mode: kernel stats + one step's timeline of the MNIST leg, every GEMM launch in isolation, L2 counters
+run rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bf16 -- python3 tools/gpu_bf16_bench.py mnist 25 > gpurun_out/${tag}_bf16.log 2>&1 && echo bf16 ok
 # conversions into the files kept under profiles/ (small; done here so that they travel back with gpurun_out/)
 sha=gpurun_out/${tag}_src_sha256.txt
 out=gpurun_out/${tag}_profiles
@@ -34,6 +36,15 @@ cp $(ls gpurun_out/${tag}_bench/*/*kernel_stats.csv | head -n 1) $out/${tag}_ben
 cp gpurun_out/${tag}_roof.json $out/${tag}_roofline_leg.json
 cp gpurun_out/${tag}_bench_under_rocprof.json $out/${tag}_bench_default_under_rocprof.json
 cp $sha $out/
+bf=$(ls gpurun_out/${tag}_bf16/*/*kernel_trace.csv 2>/dev/null | head -n 1)
+if [ -n "$bf" ]; then
+  python3 tools/step_timeline.py $bf 10 > $out/${tag}_bf16_step_timeline.txt
+  cp $(ls gpurun_out/${tag}_bf16/*/*kernel_stats.csv | head -n 1) $out/${tag}_bf16_mnist_kernel_stats.csv
+fi
+rm -rf gpurun_out/${tag}_bf16
+python3 tools/gpu_bf16_layers.py mnist > $out/${tag}_bf16_layers_mnist.txt 2>/dev/null
+python3 tools/gpu_bf16_layers.py laion64 > $out/${tag}_bf16_layers_laion64.txt 2>/dev/null
+bash tools/bf16_layer_counters.sh mnist > /dev/null 2>&1 && cp gpurun_out/bf16_layer_counters_mnist.txt $out/${tag}_bf16_layer_counters_mnist.txt
 rm -rf gpurun_out/${tag}_roof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w gpurun_out/${tag}_pmc_mfma gpurun_out/${tag}_train gpurun_out/${tag}_bench
 # the per-dispatch traces of the long legs are large (two 1000-step chains): keep the stats only
 find gpurun_out/${tag}_bench gpurun_out/${tag}_roof -name "*kernel_trace.csv" -delete 2>/dev/null
