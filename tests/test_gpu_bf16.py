@@ -261,8 +261,11 @@ def _check_against_fp32(m, args_gpu, noise, eps_ref, loss_ref, grads_ref, tag):
     assert cos[0][0] >= 0.93 and med >= 0.99, (cos[:3], med)
 
 
-def test_bf16_mnist_unet_against_fp32_golden(golden_dir):
-    """configs[1] network in bf16 mode against the reference's fp32 vectors (B = 64, train-mode BN)."""
+@pytest.mark.parametrize("materialize", [1, 0])
+def test_bf16_mnist_unet_against_fp32_golden(golden_dir, tdx, materialize):
+    """configs[1] network in bf16 mode against the reference's fp32 vectors (B = 64, train-mode BN).  materialize = 1
+    (default): relu(bn(Y)) of a unit that feeds another convolution is written out in bf16 once; 0: recomputed while
+    the consuming GEMMs stage their tiles (the same values: fp32 fma, one rounding)."""
     from tiny_diffusion_amd.diffusion import NoiseModel
 
     d = np.load(os.path.join(golden_dir, "grad_B64_uncond.npz"))
@@ -272,8 +275,12 @@ def test_bf16_mnist_unet_against_fp32_golden(golden_dir):
     m.set_compute_dtype(torch.bfloat16)
     x_t, t, noise = torch.from_numpy(d["x_t"]), torch.from_numpy(d["t"]), torch.from_numpy(d["noise"])
     _, _, g32, _ = R.train_step_grads(sd, x_t, t, noise)
-    _check_against_fp32(m, (x_t.cuda(), t.cuda()), noise, torch.from_numpy(d["eps_hat"]), float(d["loss"]), g32,
-                        "mnist B64")
+    tdx.check(tdx.lib.tdx_tune_set(b"bf16_materialize", materialize))
+    try:
+        _check_against_fp32(m, (x_t.cuda(), t.cuda()), noise, torch.from_numpy(d["eps_hat"]), float(d["loss"]), g32,
+                            f"mnist B64 materialize={materialize}")
+    finally:
+        tdx.check(tdx.lib.tdx_tune_set(b"bf16_materialize", 1))
     # and back: the same module in fp32 mode reproduces the fp32 vectors exactly as before
     m.set_compute_dtype(torch.float32)
     m.load_state_dict(sd)

@@ -225,20 +225,45 @@ bn_relu_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int64
   }
 }
 
+// the same on bf16 tensors (bf16 storage mode): eight channels per thread, fp32 arithmetic, one rounding on store -
+// the values a BN+ReLU-on-load convolution would have staged
+__global__ void __launch_bounds__(256)
+bn_relu_apply16_kernel(const tdx_bf16* __restrict__ y, tdx_bf16* __restrict__ out, int64_t n8, int C,
+                       const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int c8n = C / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8n) * 8;
+    const float4 a0 = ld4(y + i * 8), a1 = ld4(y + i * 8 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + c), h1 = *reinterpret_cast<const float4*>(shift + c + 4);
+    float4 o0, o1;
+    o0.x = fmaxf(fmaf(a0.x, s0.x, h0.x), 0.f); o0.y = fmaxf(fmaf(a0.y, s0.y, h0.y), 0.f);
+    o0.z = fmaxf(fmaf(a0.z, s0.z, h0.z), 0.f); o0.w = fmaxf(fmaf(a0.w, s0.w, h0.w), 0.f);
+    o1.x = fmaxf(fmaf(a1.x, s1.x, h1.x), 0.f); o1.y = fmaxf(fmaf(a1.y, s1.y, h1.y), 0.f);
+    o1.z = fmaxf(fmaf(a1.z, s1.z, h1.z), 0.f); o1.w = fmaxf(fmaf(a1.w, s1.w, h1.w), 0.f);
+    st4(out + i * 8, o0);
+    st4(out + i * 8 + 4, o1);
+  }
+}
+
 int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const float* scale, const float* shift,
-                      hipStream_t st) {
-  if (!y || !out || !scale || !shift || rows <= 0 || C <= 0 || C % 4) return TDX_E_BADARG;
+                      hipStream_t st, int io16) {
+  if (!y || !out || !scale || !shift || rows <= 0 || C <= 0 || C % 4 || (io16 && C % 8)) return TDX_E_BADARG;
   const int64_t n4 = rows * C / 4;
-  int grid = (int)((n4 + 255) / 256);
+  int grid = (int)(((io16 ? n4 / 2 : n4) + 255) / 256);
   if (grid > 8192) grid = 8192;
-  bn_relu_apply_kernel<<<grid, 256, 0, st>>>(y, out, n4, C, scale, shift);
+  if (io16)
+    bn_relu_apply16_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const tdx_bf16*>(y), reinterpret_cast<tdx_bf16*>(out),
+                                                 n4 / 2, C, scale, shift);
+  else
+    bn_relu_apply_kernel<<<grid, 256, 0, st>>>(y, out, n4, C, scale, shift);
   TDX_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int tdx_bn_apply_relu_fwd(const float* y, float* out, int64_t rows, int C, const float* scale,
                                      const float* shift, tdx_stream_t stream) {
-  return tdx_bn_relu_apply(y, out, rows, C, scale, shift, to_stream(stream));
+  return tdx_bn_relu_apply(y, out, rows, C, scale, shift, to_stream(stream), 0);
 }
 
 // ------------------------------------------------------------------ backward

@@ -272,36 +272,50 @@ thin_fat_wgrad_kernel(const float* __restrict__ thin, const TF* __restrict__ fat
     oh = r / W;
     ow = r - oh * W;
   }
-#pragma unroll 4
-  for (int64_t p = p0; p < p1; p += 2, q += 2) {
-    const bool qv = q < p1;
-    const TF* frow = fat + q * IC_CO + l31;
-    const float a0 = qv ? ld1(frow) : 0.f;
-    const float a1 = qv ? ld1(frow + 32) : 0.f;
-    const float* tb = thin + (int64_t)n * CT * HW + oh * W + ow;
-    float bq[CB];
+  // Eight pixel pairs per trip, every load of the trip issued before its first MFMA (branch-free: a refused tap reads
+  // the tensor's first element and is zeroed afterwards).  The loop is bound by the round trip of its 4-byte loads, not
+  // by its MFMAs: pair by pair (what hipcc makes of the plain loop, the agent-scope loads pinning the order) the
+  // initial-convolution launch took 154 us on the tail of the fp32 step for 51 MB of input.
+  constexpr int U = 8;
+  for (int64_t p = p0; p < p1; p += 2 * U) {
+    float a0[U], a1[U], bq[U][CB];
+    bool okq[U][CB], qvu[U];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      float v = 0.f;
-      if (kind[cb] == 1) v = qv ? 1.f : 0.f;
-      else if (kind[cb] != 2) {
-        const bool ok = qv && (unsigned)(oh + kdy[cb]) < (unsigned)H && (unsigned)(ow + kdx[cb]) < (unsigned)W;
+    for (int u = 0; u < U; ++u) {
+      const bool qv = q < p1;
+      qvu[u] = qv;
+      const TF* frow = fat + (qv ? q : p0) * IC_CO + l31;
+      a0[u] = ld1(frow);
+      a1[u] = ld1(frow + 32);
+      const float* tb = thin + (int64_t)n * CT * HW + oh * W + ow;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const bool ok = qv & (kind[cb] == 0 || kind[cb] == 3) & ((unsigned)(oh + kdy[cb]) < (unsigned)H) &
+                        ((unsigned)(ow + kdx[cb]) < (unsigned)W);
+        okq[u][cb] = ok;
+        const float* src = ok ? tb + koff[cb] : thin;
         // initial_conv (FLIP = false): `thin` is the workspace COPY of the model input that the forward made
         // with hipMemcpyAsync, and this kernel may run on a helper stream - the shape of the one hand-off
         // that was seen stale from one XCD: read it at agent scope (L2-served `sc1` loads,
         // 0.8 MB in all: free).  final_conv's thin operand is a kernel's output on the same stream: plain.
-        v = !ok ? 0.f : FLIP ? tb[koff[cb]] : __hip_atomic_load(tb + koff[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (FLIP && kind[cb] == 3) dbacc[cb] += v;
+        bq[u][cb] = FLIP ? *src : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      bq[cb] = v;
+      q += 2;
+      ow += 2;
+      if (ow >= W) { ow -= W; if (++oh == H) { oh = 0; ++n; } }
     }
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[cb], acc[0][cb], 0, 0, 0);
-      acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[cb], acc[1][cb], 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      const float x0 = qvu[u] ? a0[u] : 0.f, x1 = qvu[u] ? a1[u] : 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        float v = okq[u][cb] ? bq[u][cb] : 0.f;
+        if (kind[cb] == 1) v = qvu[u] ? 1.f : 0.f;
+        if (FLIP && kind[cb] == 3) dbacc[cb] += v;
+        acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, v, acc[0][cb], 0, 0, 0);
+        acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, v, acc[1][cb], 0, 0, 0);
+      }
     }
-    ow += 2;
-    if (ow >= W) { ow -= W; if (++oh == H) { oh = 0; ++n; } }
   }
 
   // waves add their tiles in wave order

@@ -105,7 +105,9 @@ int tdx_latent_tensor(int B, const char* name, size_t* off, size_t* numel);
 // run training on one stream / on the three-stream schedule
 extern int g_tdx_streams;
 int tdx_bn_relu_apply(const float* y, float* out, int64_t rows, int C, const float* scale, const float* shift,
-                      hipStream_t st);
+                      hipStream_t st, int io16 = 0);
+// tuning knob "bf16_materialize": the same in bf16 storage mode (0: BN + ReLU while the consuming GEMMs stage their tiles)
+extern int g_tdx_bf16_materialize;
 // tuning knob "materialize": 1 = the activation feeding the second convolution of a stage is
 // written out (post BN+ReLU) so that convolution and its wgrad run on the LDS-DMA kernels
 extern int g_tdx_materialize;

@@ -164,6 +164,7 @@ Layout make_layout(const NetSpec& S, int B) {
 }  // namespace
 
 int g_tdx_materialize = 1;
+int g_tdx_bf16_materialize = 1;
 int g_tdx_bf16_storage = 1;     // knob "bf16_storage": plans switched to bf16 afterwards keep their activation tensors in bf16 too
 // Sampling (INFER forward) launch fusions, knob "sample_fuse": bit 0 a split-K result consumed only by a resize is left
 // unreduced and summed by that resize on load (splits <= "sample_defer_max"), bit 1 the reduction of units 3 / 5 also
@@ -651,19 +652,26 @@ extern "C" int tdx_unet_forward(tdx_unet* u, const void* const* params, void* co
     float* Y = ws + L.Y[i];
     float* ss = ws + L.ss[i];
     if (bf16) {
-      // bf16 operands, fp32 accumulate / storage; BN+ReLU of the producing unit applied while staging
-      // (nothing is materialised: the kernel is memory-bound and its VALU is idle)
+      // bf16 operands, fp32 accumulate.  bf16 storage (round 3): relu(bn(Y)) of a unit that feeds another convolution
+      // directly is written out once (25 us of HBM time on the largest layer) instead of being recomputed by the
+      // consumer's staging path - at the bf16 matrix rate the transform's ~128 VALU instructions per K-tile were as long
+      // as the K-tile's MFMAs (forward launches with BN on load: +50 % over the same shapes with a raw input)
       const int64_t M = (int64_t)B * d.hw * d.hw;
+      const bool mat16 = io16 && u->materialize && g_tdx_bf16_materialize;
       if (infer) {
         const float* iss = u->infer_ss + u->iss_off[i];
         return tdx_conv3x3_fwd_bf16_io(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, TDX_CONV_OUT_BNRELU, nullptr,
                                        nullptr, iss, iss + d.cout, nullptr, io16, stream);
       }
-      const int fl = (d.in_bn ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
-      RC(tdx_conv3x3_fwd_bf16_io(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, d.in_bn ? sc(i - 1) : nullptr,
-                                 d.in_bn ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, io16, stream));
+      const bool on_load = d.in_bn && !mat16;
+      if (d.in_bn && mat16) in = ws + L.A[i - 1];
+      const int fl = (on_load ? TDX_CONV_IN_BNRELU : 0) | (training ? TDX_CONV_OUT_STATS : 0);
+      RC(tdx_conv3x3_fwd_bf16_io(in, wf, bias, Y, B, d.hw, d.hw, d.cin, d.cout, fl, on_load ? sc(i - 1) : nullptr,
+                                 on_load ? sh(i - 1) : nullptr, nullptr, nullptr, ws + L.stats, io16, stream));
       const int rows = tdx_conv3x3_bf16_stat_tile_rows();
       RC(finalize_bn(i, cdiv(M, rows), rows, M));
+      if (mat16 && i + 1 < 13 && S.units[i + 1].in_bn)
+        RC(tdx_bn_relu_apply(Y, ws + L.A[i], M, d.cout, ss, ss + d.cout, st, 1));
       return 0;
     }
     if (infer) {
@@ -870,8 +878,9 @@ extern "C" int tdx_unet_backward(tdx_unet* u, const void* const* params, void* c
     u->bw_unit = -1;
     // Weight gradient: forked to the side stream (which IS the main stream for networks whose
     // NetSpec says overlap = 0).
-    const bool bn_on_load = d.in_bn && (!u->materialize || bf16);
-    if (d.in_bn && u->materialize && !bf16) in = ws + L.A[i - 1];  // materialised relu(bn(Y[i-1]))
+    const bool mat = u->materialize && (!bf16 || (io16 && g_tdx_bf16_materialize));
+    const bool bn_on_load = d.in_bn && !mat;
+    if (d.in_bn && mat) in = ws + L.A[i - 1];  // materialised relu(bn(Y[i-1]))
     const float* isc = bn_on_load ? ws + L.ss[i - 1] : nullptr;
     const float* ish = bn_on_load ? ws + L.ss[i - 1] + S.units[i - 1].cout : nullptr;
     const bool fork = true;
