@@ -124,8 +124,10 @@ def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
 #   ring     + the 256-row DMA ring forward kernel where M % 256 == 0 (off by default: slower inside the step)
 #   per_tap  one workgroup per tap with the swizzled transposing stage (conv3x3_wgrad_bf16s_kernel)
 #   round2   the round-2 staging of the per-tap kernel
+#   wgs256   the nine-tap kernel with its pixel split aimed at 256 workgroups (fewer, longer chunks; off by default)
 IO16_VARIANTS = {"default": {}, "ring": {"bf16_ring": 1}, "per_tap": {"bf16_wgrad9": 0},
-                 "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}}
+                 "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}, "wgs256": {"wgrad9_wgs": 256}}
+IO16_KNOB_DEFAULTS = {"bf16_ring": 0, "bf16_wgrad9": 1, "bf16_wgrad_swz": 1, "wgrad9_wgs": 0}
 IO16_CASES = [
     # B, H, cin, cout, in_bn: M % 256 == 0 (ring) and ragged M; 4x4 .. 64x64 maps (the padded-slot ring of the nine-tap
     # kernel: 64 slots span 2.5 samples at 4x4, its halo 4 blocks at 64x64); 64- and 128-wide tiles; BN+ReLU on load
@@ -166,12 +168,12 @@ def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
     out = torch.full((B, H, H, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
     stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
     gin = torch.full((B, H, H, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
-    splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)
-    slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
     dw = torch.empty((cout, cin, 3, 3), device="cuda")
     try:
         for k, v in knobs.items():
             check(lib.tdx_tune_set(k.encode(), v))
+        splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)   # (the split plan follows wgrad9_wgs)
+        slabs = torch.full((splits, cout, 9, cin), float("nan"), device="cuda")
         check(lib.tdx_conv3x3_fwd_bf16_io(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, H, cin, cout,
                                           4 | (1 if in_bn else 0), scp, shp, None, None, stats.data_ptr(), 1, st()))
         check(lib.tdx_conv3x3_fwd_bf16_io(gd.data_ptr(), wg16.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
@@ -181,8 +183,8 @@ def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
         check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st()))
         torch.cuda.synchronize()
     finally:
-        for k in knobs:   # back to the defaults (bf16_ring 0, the others 1)
-            check(lib.tdx_tune_set(k.encode(), 0 if k == "bf16_ring" else 1))
+        for k in knobs:
+            check(lib.tdx_tune_set(k.encode(), IO16_KNOB_DEFAULTS[k]))
     # outputs are rounded to bf16 once: 2^-9 relative per element at most
     assert torch.isfinite(out.float()).all() and torch.isfinite(gin.float()).all()
     assert rel_err(nchw(out.float()), ref.detach()) < 3e-3
