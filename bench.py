@@ -600,6 +600,59 @@ def laion_extras(steps: int = 30, warmup: int = 6):
     return out
 
 
+def bf16_gemm_roofline(units, B, reps: int = 5):
+    """The 39 bf16-mode GEMM launches of one training step in isolation (bf16 storage entry points of the C ABI, HIP
+    events on the launch stream): forward, input gradient, weight gradient (GEMM into slabs + slab reduction) per
+    unit - the bf16-mode counterpart of the fp32 `roofline` block, against the bf16 matrix peak.  These kernels are
+    bound by L1 / LDS traffic, not by the matrix core: the fraction says how far."""
+    from tiny_diffusion_amd._lib import lib, check
+    dev = torch.device("cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    flop = 0.0
+    for cin, cout, H, in_bn in units:
+        M = B * H * H
+        x = torch.randn(M * cin, device=dev).to(torch.bfloat16)
+        dy = torch.randn(M * cout, device=dev).to(torch.bfloat16)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
+        wf = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(cout * 9 * cin, dtype=torch.bfloat16, device=dev)
+        check(lib.tdx_pack_conv3x3_bf16(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), cout, cin, st))
+        out = torch.empty(M * cout, dtype=torch.bfloat16, device=dev)
+        gin = torch.empty(M * cin, dtype=torch.bfloat16, device=dev)
+        stats = torch.empty(((M + 127) // 128) * 2 * cout, device=dev)
+        splits = lib.tdx_conv3x3_wgrad_splits_bf16(B, H, H, cin, cout)
+        slabs = torch.empty(splits * cout * 9 * cin, device=dev)
+        dw = torch.empty(cout * cin * 9, device=dev)
+        bias = torch.zeros(cout, device=dev)
+
+        # (the step materialises relu(bn(Y)) for the units whose input is a BatchNorm output: raw inputs here)
+        def fwd():
+            check(lib.tdx_conv3x3_fwd_bf16_io(x.data_ptr(), wf.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, H, cin,
+                                              cout, 4, None, None, None, None, stats.data_ptr(), 1, st))
+
+        def dgrad():
+            check(lib.tdx_conv3x3_fwd_bf16_io(dy.data_ptr(), wd.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
+                                              None, None, None, None, None, 1, st))
+
+        def wgrad():
+            check(lib.tdx_conv3x3_wgrad_bf16_io(x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout, 0, None,
+                                                None, 1, st))
+            check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st))
+
+        for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            tot[name] += _time_ms(fn, reps)
+        flop += 3 * 2.0 * M * 9 * cin * cout
+    ms = sum(tot.values())
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "launches_per_step": 3 * len(units),
+            "gemm_ms_per_step_isolated": round(ms, 3),
+            "by_role_ms": {k: round(v, 3) for k, v in tot.items()},
+            "kernel": "conv3x3_bf16_kernel (fwd, dgrad) + conv3x3_wgrad9_bf16_kernel + wgrad_reduce_kernel; "
+                      "weight-gradient rows = GEMM into slabs + reduction"}
+
+
 def mnist_bf16_leg(fp, steps: int = 30, warmup: int = 6):
     """The headline workload in the opt-in bf16 compute mode (same step, same batch): reported beside
     the fp32 value, never in its place."""
@@ -629,6 +682,7 @@ def mnist_bf16_leg(fp, steps: int = 30, warmup: int = 6):
             "frac_of_bf16_mfma_peak": round(v * TRAIN_FLOP_PER_IMAGE / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "roofline": bf16_hbm_roofline([(ci, co, h) for ci, co, h, _ in UNITS], PER_GPU_BATCH, 11_182_273,
                                           dt / steps * 1e3),
+            "gemm_roofline": bf16_gemm_roofline(UNITS, PER_GPU_BATCH),
             "arithmetic": "bf16 MFMA operands, fp32 accumulation; activations and activation gradients stored in bf16 "
                           "(tests/test_gpu_bf16.py)"}
 
