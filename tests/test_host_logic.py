@@ -191,3 +191,47 @@ def test_conv_descriptor_bound():
     one = C.c_void_p(16)
     assert lib.tdx_conv3x3_fwd(one, one, None, one, 2048, 32, 32, 256, 64, 0, None, None, None, None, None, None) == -2
     assert lib.tdx_conv3x3_wgrad(one, one, one, 2048, 32, 32, 256, 64, 0, None, None, None) == -2
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 4, 4, 5, 6), (2, 7, 7, 4, 3), (2, 5, 9, 3, 4), (1, 28, 28, 2, 2)])
+def test_slot_space_weight_gradient_identity(B, H, W, cin, cout):
+    """The arithmetic identity conv3x3_wgrad9_bf16_kernel is built on (csrc/conv3x3_bf16.hip), checked
+    on the host against torch's convolution weight gradient: lay every sample out as a padded (H+1) x (W+1) image with a
+    zero column after each row and a zero row after each sample, number the positions ("slots") consecutively, and
+    the (dh, dw) neighbour of slot s is slot s + dh (W+1) + dw - every out-of-image neighbour lands on a zero slot (or
+    in front of / behind the tensor), so
+        dW[co][dh][dw][ci] = sum_s dy[s][co] * x[s + dh (W+1) + dw][ci]
+    is a plain shifted inner product over ONE slot axis.  Also the block arithmetic of the kernel's input ring: a
+    64-slot K-tile plus its halo lies inside blocks t .. t+NB of 64 slots that start HALOB slots in front of it."""
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64)
+    dy = torch.randn(B, cout, H, W, generator=g, dtype=torch.float64)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(torch.nn.functional.conv2d(x, w, padding=1), w, dy)
+    PW, PH = W + 1, H + 1
+    S = B * PH * PW
+
+    def slots(t):   # (B, C, H, W) -> [S][C] with the pad slots zero
+        p = torch.zeros(B, PH, PW, t.shape[1], dtype=t.dtype)
+        p[:, :H, :W] = t.permute(0, 2, 3, 1)
+        return p.reshape(S, t.shape[1])
+
+    xs, ds = slots(x), slots(dy)
+    halo = PW + 1
+    xs_h = torch.cat([torch.zeros(halo, cin, dtype=x.dtype), xs, torch.zeros(halo, cin, dtype=x.dtype)])   # outside the tensor: zero
+    got = torch.zeros_like(ref)
+    for dh in (-1, 0, 1):
+        for dw in (-1, 0, 1):
+            sh = dh * PW + dw
+            got[:, :, dh + 1, dw + 1] = ds.t() @ xs_h[halo + sh:halo + sh + S]
+    assert torch.allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # ring geometry of the kernel (launch_wgrad9_bf16): K-tile t covers slots [64 t, 64 t + 64) of its chunk and reads
+    # input slots 64 t - PW - 1 .. 64 t + 63 + PW + 1; block b holds slots [64 b - HALOB, 64 b - HALOB + 64)
+    for Wk in (4, 7, 8, 14, 16, 28, 32, 64, 95):
+        PWk = Wk + 1
+        HALOB = (PWk + 1 + 63) // 64 * 64
+        NB = (HALOB + 64 + PWk) // 64
+        for t in range(5):
+            lo, hi = 64 * t - PWk - 1, 64 * t + 63 + PWk + 1
+            assert (lo + HALOB) // 64 >= t and (hi + HALOB) // 64 <= t + NB, (Wk, t)
+        assert (NB + 2) * 64 * 128 + 64 * 128 + 2 * 64 * 128 <= 98304   # ring + mirror + two dy tiles: the launcher's LDS cap
