@@ -125,14 +125,20 @@ def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
 #   per_tap  one workgroup per tap with the swizzled transposing stage (conv3x3_wgrad_bf16s_kernel)
 #   round2   the round-2 staging of the per-tap kernel
 #   wgs256   the nine-tap kernel with its pixel split aimed at 256 workgroups (fewer, longer chunks; off by default)
-IO16_VARIANTS = {"default": {}, "ring": {"bf16_ring": 1}, "per_tap": {"bf16_wgrad9": 0},
-                 "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}, "wgs256": {"wgrad9_wgs": 256}}
-IO16_KNOB_DEFAULTS = {"bf16_ring": 0, "bf16_wgrad9": 1, "bf16_wgrad_swz": 1, "wgrad9_wgs": 0}
+#   thin1 / thin0   the slot-window kernel for thin layers (conv3x3_bf16_thin_kernel; default: layers with 64 output or
+#            64 input channels) for 64 output channels only / nowhere
+IO16_VARIANTS = {"default": {}, "ring": {"bf16_ring": 1, "bf16_thin": 0}, "per_tap": {"bf16_wgrad9": 0},
+                 "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}, "wgs256": {"wgrad9_wgs": 256},
+                 "thin1": {"bf16_thin": 1}, "thin0": {"bf16_thin": 0}}
+IO16_KNOB_DEFAULTS = {"bf16_ring": 0, "bf16_wgrad9": 1, "bf16_wgrad_swz": 1, "wgrad9_wgs": 0, "bf16_thin": 2}
 IO16_CASES = [
     # B, H, cin, cout, in_bn: M % 256 == 0 (ring) and ragged M; 4x4 .. 64x64 maps (the padded-slot ring of the nine-tap
     # kernel: 64 slots span 2.5 samples at 4x4, its halo 4 blocks at 64x64); 64- and 128-wide tiles; BN+ReLU on load
     (16, 28, 64, 128, 0), (16, 28, 128, 128, 1), (3, 14, 128, 256, 0), (16, 4, 512, 512, 1), (5, 7, 256, 512, 0),
     (4, 8, 1024, 256, 0), (1, 64, 64, 64, 1), (2, 32, 192, 64, 0), (33, 8, 128, 128, 1), (4, 16, 384, 128, 0),
+    # thin layers (64 output or input channels, M % 256 == 0): tiles that cross sample boundaries at 28x28, whole samples
+    # inside one tile at 4x4 .. 16x16, a 64x64 map
+    (16, 28, 64, 64, 0), (16, 28, 256, 64, 0), (16, 4, 64, 64, 0), (8, 8, 64, 128, 0), (4, 16, 64, 64, 0), (1, 64, 64, 64, 0),
 ]
 
 

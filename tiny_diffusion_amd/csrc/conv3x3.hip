@@ -793,6 +793,7 @@ extern "C" int tdx_tune_set(const char* key, int value) {
   if (!strcmp(key, "input_copy")) { g_tdx_input_copy = value; return 0; }
   if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
   if (!strcmp(key, "bf16_materialize")) { g_tdx_bf16_materialize = value ? 1 : 0; return 0; }   // plans run afterwards
+  if (!strcmp(key, "bf16_thin")) { g_tdx_bf16_thin = value < 0 ? 0 : value; return 0; }   // 0 | 1 | 2: conv3x3_bf16_thin_kernel
   if (!strcmp(key, "bf16_ring")) { g_tdx_bf16_ring = value ? 1 : 0; return 0; }   // 0: 128-row register-staging bf16 GEMM everywhere
   if (!strcmp(key, "bf16_wgrad9")) { g_tdx_wgrad9 = value ? 1 : 0; return 0; }   // 0: one workgroup per tap (conv3x3_wgrad_bf16s_kernel)
   if (!strcmp(key, "bf16_wgrad_swz")) { g_tdx_wgrad_bf16s = value ? 1 : 0; return 0; }   // 0: the round-2 staging (8-way LDS store conflicts)

@@ -15,6 +15,7 @@
 // nine taps of a tile re-read their rows from L1/L2.
 #include "conv_shared.h"
 #include <type_traits>
+#include <algorithm>
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -470,6 +471,136 @@ conv3x3_bf16_ring_kernel(ConvArgs a) {
   if (a.dbg & 128) return;   // (ablation: no epilogue)
   const int h = wm >> 1;   // which 128-row half of the tile this wave belongs to
   conv_epilogue<128, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw + h * 40960), tile_m * 2 + h, m0 + 128 * h, n0,
+                                     wm & 1, wn, l31, half, tid & 255);
+#endif
+}
+
+// ------------------------------------------------- forward / input gradient, thin layers (round 3)
+// 64 output channels per workgroup: the layers at the top of the UNets (64 -> 64 at 64 x 64, 192 -> 64, 256 -> 64 ...),
+// where the kernels above sit at 5-7x their HBM time - a K-tile is ONE tap, so every input row crosses the L1 nine
+// times (24 KB of operands per 16 MFMAs of a wave).  Same idea as conv3x3_wgrad9_bf16_kernel: in slot space (padded
+// (H+1) x (W+1) images, one index) a tap is a row offset, so the input WINDOW of a 256-pixel tile - its slots plus a
+// halo of W + 2 on either side, <= 448 rows of 128 bytes - is fetched ONCE per 64-channel block by LDS-DMA and all nine
+// taps read it (row reads: each lane supplies the row of its own pixel + the tap's offset; pad slots are zero rows).
+// Only the 8 KB weight tile of a tap streams (three DMA stages, counted vmcnt + raw barrier as in the ring kernel).
+// 132 KB through the L1 per 256 pixels instead of 432.  Eight waves (4 x 2, 64 rows x 32 columns each), 80 KB of LDS:
+// two workgroups per CU.  Raw inputs only (bf16 storage mode materialises BN + ReLU).  Epilogue: conv_epilogue<128, 64>
+// by each half of the workgroup, as in the ring kernel.
+#define THIN_WROWS 448
+template <int EPI>
+__global__ void __launch_bounds__(512)
+conv3x3_bf16_thin_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 64;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* Awin = smem_raw;                          // [THIN_WROWS][128 B]
+  unsigned char* Bst = smem_raw + THIN_WROWS * 128;        // [3][64][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int xb = blockIdx.x / (8 * a.tilesN), xr = blockIdx.x % (8 * a.tilesN);
+  const int tile_m = xb * 8 + (xr & 7), tile_n = xr >> 3;
+  if (tile_m * BM >= a.M) return;   // (M % 256 == 0: no ragged tile)
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HW = a.H * a.W, PW = a.W + 1, PH = a.H + 1, PP = PH * PW, nB = a.M / HW;
+  auto slot_of = [&](int p) { const int n = p / HW, r = p - n * HW; const int oh = r / a.W; return n * PP + oh * PW + (r - oh * a.W); };
+  const int HALO = PW + 1;
+  const int wbase = slot_of(m0) - HALO;                       // slot of window row 0 (may be negative)
+  const int NR = slot_of(m0 + BM - 1) - slot_of(m0) + 1 + 2 * HALO;   // rows in use (<= THIN_WROWS: the launcher checks)
+
+  const auto rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((int64_t)a.M * a.Cin * 2), 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.Cout * 9 * a.Cin * 2, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- window fill: instruction i of wave w covers window rows (i*8 + w)*8 .. +7; lane -> row + (lane >> 3), stored
+  // chunk lane & 7 = logical chunk ^ x(row), x(r) = (r >> 1) & 7.  The slot of a row advances by 64 from i to i + 1.
+  struct Pos { int n, oh, ow; };
+  const int drow = lane >> 3, dch = lane & 7;
+  Pos w0;
+  {
+    const int s8 = wbase + wave * 8 + drow + 8 * PP;   // (+ 8 samples: the halo in front of the tensor is negative)
+    w0.n = s8 / PP - 8; const int r = s8 % PP; w0.oh = r / PW; w0.ow = r - w0.oh * PW;
+  }
+  const int dn = 64 / PP, d_oh = (64 % PP) / PW, d_ow = (64 % PP) % PW;
+  auto fill_window = [&](int cblk) {
+    Pos q = w0;
+#pragma unroll
+    for (int i = 0; i < THIN_WROWS / 64; ++i) {
+      const int r = (i * 8 + wave) * 8 + drow;
+      const bool real = (r < NR) & ((unsigned)q.n < (unsigned)nB) & (q.oh < a.H) & (q.ow < a.W);
+      const int p = (q.n * a.H + q.oh) * a.W + q.ow;
+      const unsigned off = (unsigned)p * (unsigned)a.Cin * 2u + (unsigned)(cblk * KT + ((dch ^ ((r >> 1) & 7)) << 3)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr_t)(Awin + (i * 8 + wave) * 1024), 16, real ? off : OOB, 0, 0, 0);
+      int ow = q.ow + d_ow; const bool c = ow >= PW; ow = c ? ow - PW : ow;
+      int oh = q.oh + d_oh + (c ? 1 : 0); const bool c2 = oh >= PH; oh = c2 ? oh - PH : oh;
+      q.ow = ow; q.oh = oh; q.n += dn + (c2 ? 1 : 0);
+    }
+  };
+  // weight tile of K-step k = (channel block, tap): 64 rows x 128 B, one DMA instruction per wave
+  const int brow = wave * 8 + drow;
+  const unsigned w_off = (unsigned)((n0 + brow) * 9 * a.Cin + ((dch ^ ((brow >> 1) & 7)) << 3)) * 2u;
+  const int nk = 9 * (a.Cin / KT);
+  auto issue_B = [&](int k, int st) {
+    const int kn = min(k, nk - 1);   // (requests past the end repeat the last tile into a stage nobody reads any more)
+    const int cblk = kn / 9, tap = kn - cblk * 9;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(Bst + st * 8192 + wave * 1024), 16, w_off,
+                                             (unsigned)(tap * a.Cin + cblk * KT) * 2u, 0, 0);
+  };
+
+  // ---- operand reads.  A: window row of this lane's pixel (centre tap) per 32-row block; B: row wn*32 + l31
+  int wr[2];
+#pragma unroll
+  for (int im = 0; im < 2; ++im) wr[im] = slot_of(m0 + wm * 64 + im * 32 + l31) - wbase;
+  const int x31 = (l31 >> 1) & 7;   // ((wn*32 + l31) >> 1) & 7
+  const int b_rd = (wn * 32 + l31) * 128;
+
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int im = 0; im < 2; ++im)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[im][0][r] = 0.f;
+
+  fill_window(0);
+  issue_B(0, 0);
+  issue_B(1, 1);
+  int st = 0;
+  for (int k = 0; k < nk; ++k) {
+    const int cblk = k / 9, tap = k - cblk * 9;
+    if (tap == 0) {
+      if (k > 0) {   // next channel block: everybody is done with the old window, then refill it
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fill_window(cblk);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      // weight tile k has landed when only tile k+1's instruction is outstanding; the barrier says so for every wave
+      asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
+    issue_B(k + 2, st2);
+    const int sh = (tap / 3 - 1) * PW + (tap % 3 - 1);
+    const unsigned char* Bb = Bst + st * 8192 + b_rd;
+    int arow[2], ax[2];
+#pragma unroll
+    for (int im = 0; im < 2; ++im) { arow[im] = (wr[im] + sh) * 128; ax[im] = ((wr[im] + sh) >> 1) & 7; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Bb + (((2 * ks + half) ^ x31) << 4));
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        const bf16x8 afr = *reinterpret_cast<const bf16x8*>(Awin + arow[im] + (((2 * ks + half) ^ ax[im]) << 4));
+        acc[im][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[im][0], 0, 0, 0);
+      }
+    }
+    st = st + 1 == 3 ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tail requests still in flight towards LDS
+  const int h = wm >> 1;
+  conv_epilogue<128, BN, EPI, false>(a, acc, reinterpret_cast<float*>(smem_raw + h * 24576), tile_m * 2 + h, m0 + 128 * h, n0,
                                      wm & 1, wn, l31, half, tid & 255);
 #endif
 }
@@ -1303,6 +1434,49 @@ static int launch_bf16_ring(const ConvArgs& a, int flags, hipStream_t st) {
   return 0;
 }
 
+// conv3x3_bf16_thin_kernel: 256-row x 64-column tiles, 512 threads, 80 KB of LDS.  tdx_tune_set("bf16_thin", v):
+// 0 off | 1 layers with 64 output channels | 2 (default) also layers with 64 input channels (their N tiles re-read the
+// window).  Measured (isolated, LAION 64x64, B = 256): 64 -> 64 forward 201 -> 129 us, its input gradient 151-193 ->
+// 104-144, 192 -> 64 forward 428 -> 273, its input gradient (64 -> 192) 473 -> 335; steps 9.34 -> 8.84 (1) -> 8.70 (2) ms
+// (LAION 64x64), 3.24 -> 3.09 (LAION 32x32), 4.27 -> 4.16 (MNIST).  Still 3-4x the layers' HBM time: a workgroup's 72
+// MFMAs per wave (1 us) wait for nine weight tiles one L2 round trip each - keeping the 72 KB of weights resident
+// across tiles is the next step.
+int g_tdx_bf16_thin = 2;
+static bool thin_window_fits(int H, int W) {   // the largest window of any 256-pixel tile: its slots + the halo, exactly
+  const int PW = W + 1, PP = (H + 1) * PW, HW = H * W;
+  auto slot_of = [&](int p) { const int n = p / HW, r = p - n * HW; const int oh = r / W; return n * PP + oh * PW + (r - oh * W); };
+  int worst = 0;
+  for (int j = 0; j < HW; ++j) {   // tile starts 256 j cover every phase of a sample (period HW / gcd(HW, 256) tiles)
+    const int m0 = 256 * j;
+    worst = std::max(worst, slot_of(m0 + 255) - slot_of(m0) + 1 + 2 * (PW + 1));
+    if ((m0 + 256) % HW == 0) break;
+  }
+  return worst <= THIN_WROWS;
+}
+static int launch_bf16_thin(const ConvArgs& a, int flags, hipStream_t st) {
+  const size_t lds = (size_t)THIN_WROWS * 128 + 3 * 8192;
+  const int grid = (cdiv(a.M, 256) + 7) / 8 * 8 * a.tilesN;
+  const int epi = (flags & TDX_CONV_OUT_BNRELU) ? EPI_BNRELU : (flags & TDX_CONV_OUT_STATS) ? EPI_STATS : EPI_PLAIN;
+#define TDX_LAUNCH_THIN(EPI_)                                                                        \
+  do {                                                                                               \
+    auto kern = conv3x3_bf16_thin_kernel<EPI_>;                                                      \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                            \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    kern<<<grid, 512, lds, st>>>(a);                                                                 \
+  } while (0)
+  if (epi == EPI_BNRELU) TDX_LAUNCH_THIN(EPI_BNRELU);
+  else if (epi == EPI_STATS) TDX_LAUNCH_THIN(EPI_STATS);
+  else TDX_LAUNCH_THIN(EPI_PLAIN);
+#undef TDX_LAUNCH_THIN
+  TDX_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tdx_conv3x3_fwd_bf16(const float* in, const void* wpk_bf16, const float* bias, float* out,
                                     int B, int H, int W, int cin, int cout, int flags,
                                     const float* in_scale, const float* in_shift,
@@ -1334,6 +1508,11 @@ extern "C" int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, co
   a.splits = 1; a.kt_per_split = 0; a.dbg = tdx_conv_dbg_get(); a.stamps = nullptr;
   a.out_bf16 = io16 ? 1 : 0;
   hipStream_t st = to_stream(stream);
+  if (io16 && !(flags & TDX_CONV_IN_BNRELU) && a.M % 256 == 0 && thin_window_fits(H, W) &&
+      ((g_tdx_bf16_thin >= 1 && cout == 64) || (g_tdx_bf16_thin >= 2 && cin == 64))) {
+    a.tilesN = cout / 64;
+    return launch_bf16_thin(a, flags, st);
+  }
   if (io16 && g_tdx_bf16_ring && a.M % 256 == 0 && cin <= 1024) {
     a.tilesN = cout % 128 == 0 ? cout / 128 : cout / 64;
     return cout % 128 == 0 ? launch_bf16_ring<128>(a, flags, st) : launch_bf16_ring<64>(a, flags, st);

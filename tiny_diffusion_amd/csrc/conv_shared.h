@@ -341,6 +341,6 @@ struct WgradArgs {
   int dbg;           // ablation bits of the bf16 kernels (tdx_tune_set("conv_dbg")): 16 no MFMA, 32 no LDS staging, 64 no loads
 };
 int tdx_conv_dbg_get();
-extern int g_tdx_wgrad_bf16s, g_tdx_bf16_ring, g_tdx_wgrad9;   // conv3x3_bf16.hip
+extern int g_tdx_wgrad_bf16s, g_tdx_bf16_ring, g_tdx_wgrad9, g_tdx_bf16_thin;   // conv3x3_bf16.hip
 
 void tdx_wgrad_plan(int64_t M, int cin, int cout, int* bm, int* bn, int* splits, int* chunk, bool bf16 = false);

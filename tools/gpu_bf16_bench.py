@@ -13,7 +13,7 @@ dt = torch.float32 if os.environ.get("TDX_FP32") else torch.bfloat16
 if os.environ.get("TDX_BF16_STORAGE") is not None:   # 0: bf16 MFMA operands only, fp32 tensors (the round-2 form)
     from tiny_diffusion_amd._lib import lib
     assert lib.tdx_tune_set(b"bf16_storage", int(os.environ["TDX_BF16_STORAGE"])) == 0
-for knob in ("bf16_ring", "bf16_wgrad_swz", "bf16_wgrad9", "wgrad9_wgs", "bf16_materialize"):   # TDX_TUNE_bf16_ring=0 ...: A/B of the round-3 bf16 kernels
+for knob in ("bf16_ring", "bf16_wgrad_swz", "bf16_wgrad9", "wgrad9_wgs", "bf16_materialize", "bf16_thin"):   # TDX_TUNE_bf16_ring=0 ...: A/B of the round-3 bf16 kernels
     v = os.environ.get("TDX_TUNE_" + knob)
     if v is not None:
         from tiny_diffusion_amd._lib import lib

@@ -24,6 +24,8 @@ DBG = int(os.environ.get("TDX_CONV_DBG", "0"))
 NO_REDUCE = os.environ.get("TDX_NO_REDUCE") == "1"
 if DBG:
     check(lib.tdx_tune_set(b"conv_dbg", DBG))
+if "TDX_THIN" in os.environ:        # 0 | 1 | 2: conv3x3_bf16_thin_kernel off | 64 output channels | + 64 input channels
+    check(lib.tdx_tune_set(b"bf16_thin", int(os.environ["TDX_THIN"])))
 if "TDX_WGRAD_SWZ" in os.environ:   # 0: the round-2 weight-gradient staging
     check(lib.tdx_tune_set(b"bf16_wgrad_swz", int(os.environ["TDX_WGRAD_SWZ"])))
 st = torch.cuda.current_stream().cuda_stream
