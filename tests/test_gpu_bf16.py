@@ -125,12 +125,12 @@ def test_bf16_conv_fwd_dgrad_wgrad(tdx, B, H, cin, cout):
 #   per_tap  one workgroup per tap with the swizzled transposing stage (conv3x3_wgrad_bf16s_kernel)
 #   round2   the round-2 staging of the per-tap kernel
 #   wgs256   the nine-tap kernel with its pixel split aimed at 256 workgroups (fewer, longer chunks; off by default)
-#   thin1 / thin0   the slot-window kernel for thin layers (conv3x3_bf16_thin_kernel; default: layers with 64 output or
-#            64 input channels) for 64 output channels only / nowhere
+#   thin2 / thin1 / thin0   the slot-window forward kernel (conv3x3_bf16_thin_kernel; default: every raw-input launch with
+#            M % 256 == 0) only for layers with 64 output or input channels / 64 output channels / nowhere
 IO16_VARIANTS = {"default": {}, "ring": {"bf16_ring": 1, "bf16_thin": 0}, "per_tap": {"bf16_wgrad9": 0},
                  "round2": {"bf16_wgrad9": 0, "bf16_wgrad_swz": 0}, "wgs256": {"wgrad9_wgs": 256},
-                 "thin1": {"bf16_thin": 1}, "thin0": {"bf16_thin": 0}}
-IO16_KNOB_DEFAULTS = {"bf16_ring": 0, "bf16_wgrad9": 1, "bf16_wgrad_swz": 1, "wgrad9_wgs": 0, "bf16_thin": 2}
+                 "thin2": {"bf16_thin": 2}, "thin1": {"bf16_thin": 1}, "thin0": {"bf16_thin": 0}}
+IO16_KNOB_DEFAULTS = {"bf16_ring": 0, "bf16_wgrad9": 1, "bf16_wgrad_swz": 1, "wgrad9_wgs": 0, "bf16_thin": 3}
 IO16_CASES = [
     # B, H, cin, cout, in_bn: M % 256 == 0 (ring) and ragged M; 4x4 .. 64x64 maps (the padded-slot ring of the nine-tap
     # kernel: 64 slots span 2.5 samples at 4x4, its halo 4 blocks at 64x64); 64- and 128-wide tiles; BN+ReLU on load

@@ -476,9 +476,10 @@ conv3x3_bf16_ring_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------- forward / input gradient, thin layers (round 3)
-// 64 output channels per workgroup: the layers at the top of the UNets (64 -> 64 at 64 x 64, 192 -> 64, 256 -> 64 ...),
-// where the kernels above sit at 5-7x their HBM time - a K-tile is ONE tap, so every input row crosses the L1 nine
-// times (24 KB of operands per 16 MFMAs of a wave).  Same idea as conv3x3_wgrad9_bf16_kernel: in slot space (padded
+// 64 output channels per workgroup.  Written for the layers at the top of the UNets (64 -> 64 at 64 x 64, 192 -> 64,
+// 256 -> 64 ...), where the kernels above sit at 5-7x their HBM time - a K-tile is ONE tap, so every input row crosses
+// the L1 nine times (24 KB of operands per 16 MFMAs of a wave) - and then measured faster on every other layer too
+// (knob bf16_thin): it is the bf16-storage mode's forward / input-gradient kernel wherever the rows are a multiple of 256.  Same idea as conv3x3_wgrad9_bf16_kernel: in slot space (padded
 // (H+1) x (W+1) images, one index) a tap is a row offset, so the input WINDOW of a 256-pixel tile - its slots plus a
 // halo of W + 2 on either side, <= 448 rows of 128 bytes - is fetched ONCE per 64-channel block by LDS-DMA and all nine
 // taps read it (row reads: each lane supplies the row of its own pixel + the tap's offset; pad slots are zero rows).
@@ -1435,13 +1436,14 @@ static int launch_bf16_ring(const ConvArgs& a, int flags, hipStream_t st) {
 }
 
 // conv3x3_bf16_thin_kernel: 256-row x 64-column tiles, 512 threads, 80 KB of LDS.  tdx_tune_set("bf16_thin", v):
-// 0 off | 1 layers with 64 output channels | 2 (default) also layers with 64 input channels (their N tiles re-read the
-// window).  Measured (isolated, LAION 64x64, B = 256): 64 -> 64 forward 201 -> 129 us, its input gradient 151-193 ->
-// 104-144, 192 -> 64 forward 428 -> 273, its input gradient (64 -> 192) 473 -> 335; steps 9.34 -> 8.84 (1) -> 8.70 (2) ms
-// (LAION 64x64), 3.24 -> 3.09 (LAION 32x32), 4.27 -> 4.16 (MNIST).  Still 3-4x the layers' HBM time: a workgroup's 72
-// MFMAs per wave (1 us) wait for nine weight tiles one L2 round trip each - keeping the 72 KB of weights resident
-// across tiles is the next step.
-int g_tdx_bf16_thin = 2;
+// 0 off | 1 layers with 64 output channels | 2 also layers with 64 input channels | 3 (default) every raw-input launch
+// whose rows are a multiple of 256 (wider layers run one workgroup per 64 output channels, each with its own copy of
+// the window).  Measured, B = 256: isolated (LAION 64x64) 64 -> 64 forward 201 -> 129 us, its input gradient 151-193 ->
+// 104-144, 192 -> 64 forward 428 -> 273, its input gradient (64 -> 192) 473 -> 335; steps in ms, knob 0 / 1 / 2 / 3:
+// LAION 64x64 9.34 / 8.84 / 8.65 / 8.49, LAION 32x32 3.24 / 3.11 / 3.08 / 2.96, MNIST 4.27 / 4.16 / 4.13 / 3.98.  Still
+// 3-4x the thin layers' HBM time: a workgroup's 72 MFMAs per wave (1 us) wait for nine weight tiles one L2 round trip
+// each - keeping the 72 KB of weights resident across tiles is the next step.
+int g_tdx_bf16_thin = 3;
 static bool thin_window_fits(int H, int W) {   // the largest window of any 256-pixel tile: its slots + the halo, exactly
   const int PW = W + 1, PP = (H + 1) * PW, HW = H * W;
   auto slot_of = [&](int p) { const int n = p / HW, r = p - n * HW; const int oh = r / W; return n * PP + oh * PW + (r - oh * W); };
@@ -1509,7 +1511,7 @@ extern "C" int tdx_conv3x3_fwd_bf16_io(const void* in_, const void* wpk_bf16, co
   a.out_bf16 = io16 ? 1 : 0;
   hipStream_t st = to_stream(stream);
   if (io16 && !(flags & TDX_CONV_IN_BNRELU) && a.M % 256 == 0 && thin_window_fits(H, W) &&
-      ((g_tdx_bf16_thin >= 1 && cout == 64) || (g_tdx_bf16_thin >= 2 && cin == 64))) {
+      ((g_tdx_bf16_thin >= 1 && cout == 64) || (g_tdx_bf16_thin >= 2 && cin == 64) || g_tdx_bf16_thin >= 3)) {
     a.tilesN = cout / 64;
     return launch_bf16_thin(a, flags, st);
   }
