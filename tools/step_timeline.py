@@ -39,7 +39,7 @@ for r in seg:
           f"grid {int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)}x{r['Grid_Size_Y']}")
 end = int(seg[-1]["End_Timestamp"]) - t0
 print(f"\nstep wall {end / 1e3:.1f} us, {len(seg)} kernels")
-for tag, pred in (("forward/dgrad (igemm)", lambda n: "igemm" in n or "conv3x3_bf16_kernel" in n or "conv3x3_bf16_ring" in n),
+for tag, pred in (("forward/dgrad (igemm)", lambda n: "igemm" in n or "conv3x3_bf16_kernel" in n or "conv3x3_bf16_ring" in n or "conv3x3_bf16_thin" in n),
                   ("wgrad", lambda n: "wgrad" in n)):
     print(f"  sum of {tag} kernels: {sum(e - s for s, e, n in iv if pred(n)) / 1e3:.1f} us")
 gaps, cur = [], 0
