@@ -174,6 +174,9 @@ def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
     out = torch.full((B, H, H, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
     stats = torch.full((tiles, 2, cout), float("nan"), device="cuda")
     gin = torch.full((B, H, H, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out_inf = torch.full((B, H, H, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    osc, osh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    oscd, oshd = osc.cuda(), osh.cuda()
     dw = torch.empty((cout, cin, 3, 3), device="cuda")
     try:
         for k, v in knobs.items():
@@ -184,6 +187,10 @@ def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
                                           4 | (1 if in_bn else 0), scp, shp, None, None, stats.data_ptr(), 1, st()))
         check(lib.tdx_conv3x3_fwd_bf16_io(gd.data_ptr(), wg16.data_ptr(), None, gin.data_ptr(), B, H, H, cout, cin, 0,
                                           None, None, None, None, None, 1, st()))
+        # the inference epilogue relu((acc + bias) * scale + shift) of the same launch (flag 2)
+        check(lib.tdx_conv3x3_fwd_bf16_io(xin.data_ptr(), wf16.data_ptr(), bd.data_ptr(), out_inf.data_ptr(), B, H, H, cin,
+                                          cout, 2 | (1 if in_bn else 0), scp, shp, oscd.data_ptr(), oshd.data_ptr(), None, 1,
+                                          st()))
         check(lib.tdx_conv3x3_wgrad_bf16_io(xin.data_ptr(), gd.data_ptr(), slabs.data_ptr(), B, H, H, cin, cout,
                                             1 if in_bn else 0, scp, shp, 1, st()))
         check(lib.tdx_conv3x3_wgrad_reduce(slabs.data_ptr(), dw.data_ptr(), splits, cout, cin, st()))
@@ -196,6 +203,8 @@ def test_bf16_storage_kernels(tdx, variant, B, H, cin, cout, in_bn):
     assert rel_err(nchw(out.float()), ref.detach()) < 3e-3
     assert (nchw(out.float()).double().cpu() - ref.detach()).abs().max() <= 2.0 ** -8 * ref.detach().abs().max() + 1e-6
     assert rel_err(nchw(gin.float()), ref_dx) < 3e-3
+    ref_inf = F.relu(ref.detach() * osc.double().view(1, -1, 1, 1) + osh.double().view(1, -1, 1, 1))
+    assert torch.isfinite(out_inf.float()).all() and rel_err(nchw(out_inf.float()), ref_inf) < 3e-3
     # the statistics partials come from the fp32 accumulators, not from the rounded output
     flat = ref.detach().permute(0, 2, 3, 1).reshape(-1, cout)
     for ti in range(tiles):
