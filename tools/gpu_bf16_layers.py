@@ -2,6 +2,8 @@
 """Every bf16-mode GEMM launch of one training step in isolation (bf16 storage forms, HIP events): per unit forward,
 input gradient and weight gradient (+ slab reduction), with both yardsticks - the bf16 matrix peak (2.5 PFLOP/s) and
 the HBM time of the launch's algorithmic bytes at 8 TB/s.   usage: gpu_bf16_layers.py [mnist|laion32|laion64] [B]
+Inputs are raw, as in the training step since it materialises relu(bn(Y)) (knob bf16_materialize); TDX_ONLOAD=1 applies
+BN + ReLU while staging on the units marked in_bn (the step with bf16_materialize = 0).
 Environment: TDX_CONV_DBG = ablation bits of the bf16 kernels (16 no MFMA, 32 no LDS staging, 64 no loads in the main
 loop: results are wrong, only the times mean something), TDX_NO_REDUCE=1 leaves the slab reduction out of `wgrad`."""
 import os, sys
@@ -46,6 +48,7 @@ for cin, cout, H, in_bn in units:
     dw = torch.empty(cout * cin * 9, device=dev)
     bias = torch.zeros(cout, device=dev)
     isc, ish = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
+    in_bn = in_bn if os.environ.get("TDX_ONLOAD") == "1" else 0
     scp, shp = (isc.data_ptr(), ish.data_ptr()) if in_bn else (None, None)
     fl = 4 | (1 if in_bn else 0)
 
